@@ -1,0 +1,247 @@
+/*
+ * mbd_hip.h — C ABI of libmbd_hip.so: the MI355X-native reverse-diffusion sampling loop of
+ * LeCAR-Lab/model-based-diffusion (mbd/planners/mbd_planner.py:84-148,179-180).
+ *
+ * Every entry point below replaces one piece of the reference's (pure Python/JAX) plugin surface; the
+ * reference file:line it stands in for is cited on each declaration.  The reference has no FFI of its own —
+ * the binding a maintainer would add is the ctypes stub shown in INTEGRATION.md (and shipped as
+ * model-based-diffusion_amd/mbd_hip/_capi.py).
+ *
+ * Conventions
+ *   - plain C types only; every function returns int (0 = MBD_OK, <0 = mbd_status); no exceptions/aborts
+ *     cross the ABI; mbd_last_error() returns a thread-local message for the last failure.
+ *   - pointers named d_* are DEVICE pointers (HBM, caller-owned, e.g. torch.Tensor.data_ptr()); all other
+ *     pointers are HOST pointers. The library never keeps a caller pointer after return.
+ *   - `stream` is a hipStream_t passed as void* (NULL = the default stream). Functions taking a stream are
+ *     asynchronous w.r.t. the host unless documented otherwise.
+ *   - all floating point data is IEEE float32, all PRNG words uint32 (reference: everything is f32,
+ *     mbd_planner.py:13-14 keeps x64 disabled).
+ *   - a handle is not thread-safe; distinct handles are independent.
+ */
+#ifndef MBD_HIP_H
+#define MBD_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------ */
+/* status codes                                                                                      */
+/* ------------------------------------------------------------------------------------------------ */
+typedef enum mbd_status {
+  MBD_OK = 0,
+  MBD_ERR_INVALID = -1,     /* bad argument (shape, NULL, range)                                     */
+  MBD_ERR_UNSUPPORTED = -2, /* env name / model feature outside the hot-path scope (-> ValueError)   */
+  MBD_ERR_HIP = -3,         /* a HIP runtime call failed; message carries hipGetErrorString           */
+  MBD_ERR_NO_DEVICE = -4,   /* no gfx950 device visible: the product path NEVER falls back to a CPU  */
+  MBD_ERR_STATE = -5        /* call sequence error (e.g. plan used after destroy)                    */
+} mbd_status;
+
+/* ------------------------------------------------------------------------------------------------ */
+/* compiled rigid-body model ("sys")                                                                 */
+/* ------------------------------------------------------------------------------------------------ */
+/* What brax.io.mjcf.load returns as a `System` pytree (call sites mbd/envs/humanoidrun.py:15,
+ * hopper.py:14, humanoidtrack.py:16) flattened to one POD struct.  It is produced on the host by
+ * mbd_hip/mjcf.py (or loaded from a committed .json) and handed to mbd_env_create_model().
+ * Frames: every link carries a centre-of-mass frame whose ORIENTATION equals the link frame
+ * (offset `com` only), so inverse inertia is a full symmetric body-frame tensor. */
+#define MBD_MAX_LINKS 16
+#define MBD_MAX_Q 40
+#define MBD_MAX_ACT 24
+#define MBD_MAX_COL 8
+#define MBD_MAX_TRACK 8
+
+enum mbd_reward_kind {
+  MBD_REW_HUMANOIDRUN = 0,   /* mbd/envs/humanoidrun.py:46-51                                        */
+  MBD_REW_HOPPER = 1,        /* mbd/envs/hopper.py:57-65                                             */
+  MBD_REW_HALFCHEETAH = 2,   /* brax.envs.half_cheetah (absent from the reference tree)              */
+  MBD_REW_HUMANOIDTRACK = 3  /* mbd/envs/humanoidtrack.py:87-96 (computed from the INCOMING state)   */
+};
+
+typedef struct mbd_model {
+  /* sizes */
+  int32_t n_links, n_q, n_qd, n_act, n_col, n_track, n_frames, reward_kind;
+  int32_t iso_inertia; /* 1: every inv_inertia is s*identity (spring_inertia_scale = 1 models)    */
+  int32_t reserved_i[3];
+  /* solver scalars */
+  float dt;            /* physics substep (opt.timestep); control dt = dt * n_frames                */
+  float vel_fac;       /* exp(vel_damping * dt)                                                     */
+  float ang_fac;       /* exp(ang_damping * dt)                                                     */
+  float joint_scale_pos, joint_scale_ang, collide_scale;
+  float friction, elasticity;
+  float gravity[3];
+  float reset_noise;   /* U(-reset_noise, reset_noise) on q and qd at reset; 0 = deterministic     */
+  float reward_params[8];
+  /* per link */
+  int32_t parent[MBD_MAX_LINKS];  /* -1 = world                                                    */
+  int32_t n_rot[MBD_MAX_LINKS];   /* hinge dofs of the link's joint (0..3); -1 = free joint        */
+  int32_t n_slide[MBD_MAX_LINKS]; /* slide dofs (0..3), listed before the hinges in q              */
+  int32_t q_idx[MBD_MAX_LINKS], qd_idx[MBD_MAX_LINKS];
+  float inv_mass[MBD_MAX_LINKS];
+  float inv_inertia[MBD_MAX_LINKS][6]; /* xx yy zz xy xz yz, link frame, about the COM             */
+  float com[MBD_MAX_LINKS][3];         /* COM in the link frame                                    */
+  float ap_pos[MBD_MAX_LINKS][3], ap_rot[MBD_MAX_LINKS][4]; /* joint frame on the parent, in the
+                                                               parent's COM frame (world if -1)   */
+  float ac_pos[MBD_MAX_LINKS][3], ac_rot[MBD_MAX_LINKS][4]; /* joint frame on the child, in the
+                                                               child's COM frame                  */
+  float ang_damp[MBD_MAX_LINKS], vel_damp[MBD_MAX_LINKS];   /* constraint_{ang,vel}_damping        */
+  float rot_lo[MBD_MAX_LINKS][3], rot_hi[MBD_MAX_LINKS][3]; /* limits on the joint-frame Euler
+                                                               angles (x, y', z''), radians       */
+  float rot_stiff[MBD_MAX_LINKS][3], rot_damp[MBD_MAX_LINKS][3];
+  float rot_sign[MBD_MAX_LINKS][3]; /* q_k = rot_sign_k * euler_k (handedness of the MJCF axes)    */
+  float slide_axis[MBD_MAX_LINKS][3][3]; /* slide axes in the joint frame                          */
+  /* actuators (brax.actuator.to_tau: clip to ctrlrange, * gear, scatter to the dof)               */
+  int32_t act_link[MBD_MAX_ACT];
+  int32_t act_slot[MBD_MAX_ACT]; /* 0..2 hinge k, 3..5 slide k                                     */
+  float act_gear[MBD_MAX_ACT], act_lo[MBD_MAX_ACT], act_hi[MBD_MAX_ACT];
+  /* sphere colliders vs the z = 0 plane                                                            */
+  int32_t col_link[MBD_MAX_COL];
+  float col_pos[MBD_MAX_COL][3]; /* sphere centre in the link's COM frame                          */
+  float col_radius[MBD_MAX_COL];
+  /* forward kinematics (reset only; kinematics.forward)                                            */
+  float link_pos[MBD_MAX_LINKS][3], link_rot[MBD_MAX_LINKS][4]; /* link frame in the parent frame  */
+  float joint_pos[MBD_MAX_LINKS][3];     /* joint anchor in the link frame                         */
+  float rot_axis[MBD_MAX_LINKS][3][3];   /* hinge axes in the link frame                           */
+  float slide_axis_body[MBD_MAX_LINKS][3][3];
+  float init_q[MBD_MAX_Q];
+  /* demo tracking (humanoidtrack.py:26-28)                                                         */
+  int32_t track_link[MBD_MAX_TRACK];
+} mbd_model_t;
+
+/* Dynamic state of one environment = per link 13 floats: COM position p[3], orientation quaternion
+ * r[4] = (w,x,y,z), linear velocity v[3], angular velocity w[3] (world frame).  This is brax's
+ * positional State.x_i / State.xd_i — the only quantities integrated from step to step. Layout of a
+ * state buffer: float[n_links][13].  car2d's state is float[3] = (x, y, theta) (car2d.py:35-40). */
+#define MBD_LINK_STATE 13
+
+/* ------------------------------------------------------------------------------------------------ */
+/* library                                                                                           */
+/* ------------------------------------------------------------------------------------------------ */
+const char* mbd_last_error(void);
+int mbd_version(void);
+/* number of usable gfx950 devices (0 on a box without a GPU — every compute entry then returns
+ * MBD_ERR_NO_DEVICE; there is deliberately no CPU fallback in this library). */
+int mbd_device_count(int* count);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* JAX PRNG (threefry2x32) — replaces jax.random.{PRNGKey,split} at mbd_planner.py:40,79,103,150    */
+/* host-side, pure integer arithmetic, no device needed.                                             */
+/* ------------------------------------------------------------------------------------------------ */
+enum mbd_prng_impl {
+  MBD_PRNG_LEGACY = 0,       /* jax_threefry_partitionable = False (JAX < 0.5.0 default)            */
+  MBD_PRNG_PARTITIONABLE = 1 /* jax_threefry_partitionable = True  (JAX >= 0.5.0 default)           */
+};
+int mbd_prng_key(uint64_t seed, uint32_t key_out[2]);
+int mbd_prng_split(const uint32_t key[2], int num, int impl, uint32_t* keys_out /* [num][2] */);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* environments — replaces mbd.envs.get_env (mbd/envs/__init__.py:13-33) and the env methods the    */
+/* planner uses: reset (mbd_planner.py:75,80), step (:74), action_size/observation_size (:71-72),   */
+/* eval_xref_logpd (:118), rew_xref (:121)                                                           */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct mbd_env mbd_env;
+
+/* car2d needs no model; `env_name` must be "car2d" (mbd/envs/car2d.py:43-71).  xref = demo path
+ * [50][2] float32 (car2d_xref.npy cast to f32) or NULL when demos are not used. */
+int mbd_env_create_car2d(int device, const float* xref, mbd_env** out);
+/* rigid-body envs: humanoidrun / humanoidtrack / hopper / halfcheetah — the caller passes the
+ * compiled model. xref = [n_track][50][3] float32 demo body positions or NULL. rew_xref as
+ * humanoidtrack.py:44. */
+int mbd_env_create_model(const char* env_name, int device, const mbd_model_t* model,
+                         const float* xref, float rew_xref, mbd_env** out);
+int mbd_env_destroy(mbd_env* env);
+
+/* action_size / observation_size / state record size (floats) / H limit of the demo (0 = none)   */
+int mbd_env_info(const mbd_env* env, int* action_size, int* observation_size, int* state_size,
+                 int* n_links, int* n_frames, float* dt);
+/* reset(rng) -> state (humanoidrun.py:19-32, hopper.py:20-34, humanoidtrack.py:48-61, car2d.py:73-75).
+ * Host computation (forward kinematics once per run). state_out: float[state_size] HOST. */
+int mbd_env_reset(const mbd_env* env, const uint32_t key[2], int prng_impl, float* state_out);
+/* step(state, action) -> (state', reward) for ONE environment (rendering / verification path,
+ * mbd_planner.py:163; utils.py:23-33).  Runs the same HIP rollout kernel with B=1,H=1; synchronous.
+ * All pointers HOST. obs_out may be NULL. */
+int mbd_env_step(mbd_env* env, const float* state_in, const float* action, float* state_out,
+                 float* reward_out, float* obs_out);
+/* rew_xref (car2d.py:71, humanoidtrack.py:44) */
+int mbd_env_rew_xref(const mbd_env* env, float* out);
+
+/* Batched rollout = jax.vmap(rollout_us, in_axes=(None,0)) (mbd_planner.py:109, utils.py:14-20).
+ *   d_state0 : [state_size]        one initial state shared by all B candidates
+ *   d_us     : [B][H][Nu]          action sequences
+ *   d_rewss  : [B][H]              reward after every control step
+ *   d_xpos   : [B][H][K][3] or NULL  world positions of the K tracked links after every step
+ *                                  (car2d: [B][H][3] = q).  Only what eval_xref_logpd consumes of the
+ *                                  reference's `pipline_states` output.
+ *   d_state_final : [B][state_size] or NULL
+ * asynchronous on `stream`. */
+int mbd_env_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B, int H,
+                    float* d_rewss, float* d_xpos, float* d_state_final, void* stream);
+
+/* ------------------------------------------------------------------------------------------------ */
+/* planner fast path — replaces reverse_once / reverse / run_diffusion (mbd_planner.py:97-151,179)  */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct mbd_plan mbd_plan;
+
+typedef struct mbd_plan_config {
+  int32_t Nsample;     /* GLOBAL number of candidates N (Args.Nsample, mbd_planner.py:29)           */
+  int32_t Hsample;     /* horizon H (Args.Hsample :30)                                              */
+  int32_t Ndiffuse;    /* diffusion steps (Args.Ndiffuse :31)                                       */
+  float temp_sample;   /* (:32)                                                                     */
+  float beta0, betaT;  /* (:33-34)                                                                  */
+  int32_t enable_demo; /* (:35)                                                                     */
+  int32_t prng_impl;   /* mbd_prng_impl                                                             */
+  int32_t shard_begin; /* this process owns candidates [shard_begin, shard_begin + shard_count)     */
+  int32_t shard_count; /* = Nsample on one GPU                                                      */
+  int32_t literal_score; /* 1: evaluate score/Yim1/Ybar_im1 literally (:130-133); 0: use identity   */
+  int32_t reserved[5];
+} mbd_plan_config;
+
+int mbd_plan_create(mbd_env* env, const mbd_plan_config* cfg, mbd_plan** out);
+int mbd_plan_destroy(mbd_plan* plan);
+/* noise schedule (mbd_planner.py:84-87): copies alphas, alphas_bar, sigmas ([Ndiffuse] each, HOST) */
+int mbd_plan_schedule(const mbd_plan* plan, float* alphas, float* alphas_bar, float* sigmas);
+/* state_init = reset(rng_reset) (mbd_planner.py:79-80): uploads a HOST state to the plan */
+int mbd_plan_set_state0(mbd_plan* plan, const float* state0);
+
+/* ---- one reverse-diffusion step, split at the (only) exchange point so that N can be sharded ---- */
+/* phase 1 (mbd_planner.py:103-110): eps -> Y0s = clip(eps*sigma_i + Ybar_i) for the local shard,
+ * rollout, rews = mean_H(rewss) [+ demo log-densities].  d_Ybar_i [H][Nu] (device, read), key_sample
+ * is Y0s_rng of (:103).  Writes d_rews_local [shard_count] and, with demos, d_logpd_local
+ * [shard_count] (else may be NULL).  async on stream. */
+int mbd_plan_sample_rollout(mbd_plan* plan, int i, const uint32_t key_sample[2],
+                            const float* d_Ybar_i, float* d_rews_local, float* d_logpd_local,
+                            void* stream);
+/* phase 2 (mbd_planner.py:111-135): from ALL N rewards (after the all-gather) standardise, demo
+ * blend, softmax, weighted mean over all N candidates (noise regenerated from the counter-based PRNG,
+ * so the result is bit-identical on every rank and for every shard layout), score update.
+ * Writes d_Ybar_im1 [H][Nu] and d_rew_mean [1] (= rews.mean(), :135). async on stream. */
+int mbd_plan_score_update(mbd_plan* plan, int i, const uint32_t key_sample[2], const float* d_Ybar_i,
+                          const float* d_rews_all, const float* d_logpd_all, float* d_Ybar_im1,
+                          float* d_rew_mean, void* stream);
+/* single-GPU convenience = reverse_once (mbd_planner.py:97-135): phase 1 + phase 2 on `stream`;
+ * key_inout is advanced exactly as `rng, Y0s_rng = split(rng)` (:103). async; d_Ybar updated in
+ * place; d_rew_mean [1]. */
+int mbd_plan_reverse_once(mbd_plan* plan, int i, uint32_t key_inout[2], float* d_Ybar,
+                          float* d_rew_mean, void* stream);
+/* whole reverse loop = reverse() (mbd_planner.py:138-148) + final evaluation (:179-180).
+ * key = rng_exp of (:150).  mu_0ts_out HOST [Ndiffuse-1][H][Nu] (the array saved at :156),
+ * rew_means_out HOST [Ndiffuse-1] (the tqdm postfix values, :147) — either may be NULL.
+ * Synchronous; one device->host copy at the end instead of the reference's per-step sync. */
+int mbd_plan_run(mbd_plan* plan, const uint32_t key[2], float* mu_0ts_out, float* rew_means_out,
+                 float* rew_final_out, double* loop_seconds_out);
+/* rew_final = rollout_us(state_init, Y).mean() for one plan Y [H][Nu] HOST (mbd_planner.py:179-180) */
+int mbd_plan_eval(mbd_plan* plan, const float* Y, float* rew_final_out);
+
+/* device buffers the plan owns (for inspection / parity tests): Y0s [shard][H][Nu], rewss [shard][H] */
+int mbd_plan_peek(mbd_plan* plan, float* Y0s_out, float* rewss_out, float* weights_out);
+/* timing of the dominant (rollout) kernel measured with hipEvents on the launch stream:
+ * average milliseconds per launch since the last reset; count = launches. reset != 0 clears. */
+int mbd_plan_kernel_time(mbd_plan* plan, float* avg_ms_out, int* count_out, int reset);
+int mbd_plan_enable_timing(mbd_plan* plan, int enable);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MBD_HIP_H */

@@ -1,0 +1,476 @@
+"""MJCF -> compiled positional-dynamics model (host side, numpy only).
+
+Stands in for ``brax.io.mjcf.load`` as called by the reference's envs (mbd/envs/humanoidrun.py:15,
+humanoidtrack.py:16, hopper.py:13-14) for the subset of MJCF those models use: one top-level
+``<default>``, capsule/sphere geoms, free/hinge/slide joints, motor actuators, a floor plane, and
+Brax's ``<custom><numeric>`` solver parameters (mbd/assets/humanoidrun.xml:10-23).
+
+What MuJoCo's compiler contributes inside ``mjcf.load`` is restated here from the MuJoCo
+documentation (third-party, absent from this container): ``inertiafromgeom`` masses/inertias at
+density 1000, ``fromto`` capsules, degree angles, default classes.  What Brax adds: joint-less bodies
+are fused into their parent, one *link* per remaining body, link/joint frames, and the
+``spring_mass_scale`` / ``spring_inertia_scale`` exponents applied to mass and principal inertias
+(brax/com.py) — with the humanoid's ``spring_inertia_scale = 1`` every inertia tensor becomes the
+identity.
+
+PARITY UNPINNED: none of this can be checked against a Brax/MuJoCo install here; the unit tests pin it
+against closed-form masses, centres of mass and inertias instead (tests/test_mjcf.py).
+"""
+from __future__ import annotations
+
+import math
+import xml.etree.ElementTree as ET
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from .model import (MAX_ACT, MAX_COL, MAX_LINKS, MAX_Q, MAX_TRACK, Model, REWARD_KINDS)
+
+# defaults of brax.io.mjcf.load for <custom><numeric> entries that are absent (recollection)
+_CUSTOM_DEFAULTS = {
+    "vel_damping": 0.0, "ang_damping": 0.0, "joint_scale_pos": 0.5, "joint_scale_ang": 0.2,
+    "collide_scale": 1.0, "spring_mass_scale": 0.0, "spring_inertia_scale": 0.0, "elasticity": 0.0,
+    "constraint_stiffness": 2000.0, "constraint_limit_stiffness": 1000.0,
+    "constraint_vel_damping": 0.0, "constraint_ang_damping": 0.0,
+}
+_BIG = 1.0e9
+
+
+# ---- small float64 rotation helpers ---------------------------------------------------------------
+def _qmul(a, b):
+    w = a[0] * b[0] - a[1] * b[1] - a[2] * b[2] - a[3] * b[3]
+    x = a[0] * b[1] + a[1] * b[0] + a[2] * b[3] - a[3] * b[2]
+    y = a[0] * b[2] - a[1] * b[3] + a[2] * b[0] + a[3] * b[1]
+    z = a[0] * b[3] + a[1] * b[2] - a[2] * b[1] + a[3] * b[0]
+    return np.array([w, x, y, z])
+
+
+def _qconj(q):
+    return np.array([q[0], -q[1], -q[2], -q[3]])
+
+
+def _q2mat(q):
+    q = np.asarray(q, float) / np.linalg.norm(q)
+    w, x, y, z = q
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+        [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+        [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def _mat2q(m):
+    m = np.asarray(m, float)
+    t = np.trace(m)
+    if t > 0:
+        s = math.sqrt(t + 1.0) * 2
+        q = [0.25 * s, (m[2, 1] - m[1, 2]) / s, (m[0, 2] - m[2, 0]) / s, (m[1, 0] - m[0, 1]) / s]
+    elif m[0, 0] > m[1, 1] and m[0, 0] > m[2, 2]:
+        s = math.sqrt(1.0 + m[0, 0] - m[1, 1] - m[2, 2]) * 2
+        q = [(m[2, 1] - m[1, 2]) / s, 0.25 * s, (m[0, 1] + m[1, 0]) / s, (m[0, 2] + m[2, 0]) / s]
+    elif m[1, 1] > m[2, 2]:
+        s = math.sqrt(1.0 + m[1, 1] - m[0, 0] - m[2, 2]) * 2
+        q = [(m[0, 2] - m[2, 0]) / s, (m[0, 1] + m[1, 0]) / s, 0.25 * s, (m[1, 2] + m[2, 1]) / s]
+    else:
+        s = math.sqrt(1.0 + m[2, 2] - m[0, 0] - m[1, 1]) * 2
+        q = [(m[1, 0] - m[0, 1]) / s, (m[0, 2] + m[2, 0]) / s, (m[1, 2] + m[2, 1]) / s, 0.25 * s]
+    q = np.array(q)
+    q = q / np.linalg.norm(q)
+    return q if q[0] >= 0 else -q
+
+
+def _from_to(a, b):
+    """Shortest-arc quaternion rotating unit vector a onto unit vector b (brax math.from_to)."""
+    a = np.asarray(a, float) / np.linalg.norm(a)
+    b = np.asarray(b, float) / np.linalg.norm(b)
+    d = float(np.dot(a, b))
+    if d > 1 - 1e-12:
+        return np.array([1.0, 0, 0, 0])
+    if d < -1 + 1e-12:
+        o = np.cross(a, [0.0, 0.0, 1.0])
+        if np.linalg.norm(o) < 1e-6:
+            o = np.cross(a, [0.0, 1.0, 0.0])
+        o = o / np.linalg.norm(o)
+        return np.array([0.0, *o])
+    c = np.cross(a, b)
+    q = np.array([1.0 + d, *c])
+    return q / np.linalg.norm(q)
+
+
+def _rot(v, q):
+    return _q2mat(q) @ np.asarray(v, float)
+
+
+def _floats(s: Optional[str], n: Optional[int] = None, default=None):
+    if s is None:
+        return default
+    v = [float(t) for t in s.split()]
+    if n is not None and len(v) != n:
+        raise ValueError(f"expected {n} numbers, got {s!r}")
+    return np.array(v)
+
+
+# ---- geoms -----------------------------------------------------------------------------------------
+class _Geom:
+    def __init__(self, kind, pos, quat, radius, half, density, contype, conaffinity, friction, name):
+        self.kind, self.pos, self.quat = kind, np.asarray(pos, float), np.asarray(quat, float)
+        self.radius, self.half, self.density = radius, half, density
+        self.contype, self.conaffinity, self.friction, self.name = contype, conaffinity, friction, name
+
+    def mass_inertia(self):
+        """(mass, inertia about the geom centre in the BODY frame) — MuJoCo inertiafromgeom."""
+        r, h, rho = self.radius, self.half, self.density
+        if self.kind == "sphere":
+            m = rho * 4.0 / 3.0 * math.pi * r ** 3
+            local = np.eye(3) * (0.4 * m * r * r)
+        elif self.kind == "capsule":
+            mc = rho * math.pi * r * r * (2 * h)
+            ms = rho * 4.0 / 3.0 * math.pi * r ** 3
+            m = mc + ms
+            izz = mc * r * r / 2 + ms * 0.4 * r * r
+            ixx = mc * ((2 * h) ** 2 / 12 + r * r / 4) + ms * (0.4 * r * r + h * h + 0.75 * h * r)
+            local = np.diag([ixx, ixx, izz])
+        else:
+            raise ValueError(f"geom type {self.kind!r} is outside the hot-path subset")
+        R = _q2mat(self.quat)
+        return m, R @ local @ R.T
+
+    def transformed(self, pos, quat):
+        """The same geom expressed in the parent frame of a body at (pos, quat)."""
+        return _Geom(self.kind, np.asarray(pos) + _rot(self.pos, quat), _qmul(quat, self.quat),
+                     self.radius, self.half, self.density, self.contype, self.conaffinity,
+                     self.friction, self.name)
+
+    def sphere_points(self):
+        """Sphere colliders this geom contributes against a plane (capsule = its two end spheres)."""
+        if self.kind == "sphere":
+            return [(self.pos, self.radius)]
+        if self.kind == "capsule":
+            ax = _rot([0, 0, self.half], self.quat)
+            return [(self.pos + ax, self.radius), (self.pos - ax, self.radius)]
+        raise ValueError(self.kind)
+
+
+class _Body:
+    def __init__(self, name, pos, quat):
+        self.name, self.pos, self.quat = name, np.asarray(pos, float), np.asarray(quat, float)
+        self.joints: List[dict] = []
+        self.geoms: List[_Geom] = []
+        self.children: List["_Body"] = []
+
+
+def _merged(defaults: Dict[str, Dict[str, str]], tag: str, elem) -> Dict[str, str]:
+    d = dict(defaults.get(tag, {}))
+    d.update(elem.attrib)
+    return d
+
+
+def _parse_geom(elem, defaults, angle_scale) -> Optional[_Geom]:
+    a = _merged(defaults, "geom", elem)
+    kind = a.get("type", "sphere")
+    if kind == "plane":
+        return None
+    size = _floats(a.get("size"), None, np.array([0.0]))
+    quat = _floats(a.get("quat"), 4, np.array([1.0, 0, 0, 0]))
+    if "axisangle" in a:
+        aa = _floats(a["axisangle"], 4)
+        ang = aa[3] * angle_scale
+        ax = aa[:3] / np.linalg.norm(aa[:3])
+        quat = np.array([math.cos(ang / 2), *(math.sin(ang / 2) * ax)])
+    pos = _floats(a.get("pos"), 3, np.zeros(3))
+    half = 0.0
+    if kind == "capsule":
+        if "fromto" in a:
+            ft = _floats(a["fromto"], 6)
+            p0, p1 = ft[:3], ft[3:]
+            pos = 0.5 * (p0 + p1)
+            half = 0.5 * float(np.linalg.norm(p1 - p0))
+            quat = _from_to([0, 0, 1.0], (p1 - p0))
+        else:
+            half = float(size[1])
+    elif kind != "sphere":
+        raise ValueError(f"geom type {kind!r} is outside the hot-path subset (sphere, capsule)")
+    fr = _floats(a.get("friction"), None, np.array([1.0, 0.005, 0.0001]))
+    return _Geom(kind, pos, quat, float(size[0]), half, float(a.get("density", 1000.0)),
+                 int(a.get("contype", 1)), int(a.get("conaffinity", 1)), float(fr[0]),
+                 a.get("name", ""))
+
+
+def _parse_body(elem, defaults, angle_scale) -> _Body:
+    b = _Body(elem.get("name", ""), _floats(elem.get("pos"), 3, np.zeros(3)),
+              _floats(elem.get("quat"), 4, np.array([1.0, 0, 0, 0])))
+    b.quat = b.quat / np.linalg.norm(b.quat)
+    for ch in elem:
+        if ch.tag == "joint" or ch.tag == "freejoint":
+            a = _merged(defaults, "joint", ch) if ch.tag == "joint" else dict(ch.attrib, type="free")
+            b.joints.append(a)
+        elif ch.tag == "geom":
+            g = _parse_geom(ch, defaults, angle_scale)
+            if g is not None:
+                b.geoms.append(g)
+        elif ch.tag == "body":
+            b.children.append(_parse_body(ch, defaults, angle_scale))
+    return b
+
+
+def _fuse(b: _Body) -> None:
+    """Brax fuses joint-less bodies into their parent (feet -> shins in the humanoid)."""
+    new_children: List[_Body] = []
+    for c in b.children:
+        _fuse(c)
+        if not c.joints:
+            for g in c.geoms:
+                b.geoms.append(g.transformed(c.pos, c.quat))
+            for gc in c.children:
+                gc.pos = c.pos + _rot(gc.pos, c.quat)
+                gc.quat = _qmul(c.quat, gc.quat)
+                new_children.append(gc)
+        else:
+            new_children.append(c)
+    b.children = new_children
+
+
+def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Optional[str] = None,
+         track_names: Sequence[str] = (), reset_noise: float = 0.0,
+         reward_params: Sequence[float] = ()) -> Model:
+    """Compile an MJCF file. ``n_frames`` is the env's physics substeps per control step
+    (humanoidrun.py:17 -> 7, humanoidtrack.py:46 -> 5, hopper.py:18 -> 20)."""
+    root = ET.parse(path).getroot()
+    comp = root.find("compiler")
+    angle_scale = 1.0 if (comp is not None and comp.get("angle", "degree") == "radian") else math.pi / 180
+    defaults: Dict[str, Dict[str, str]] = {}
+    dflt = root.find("default")
+    if dflt is not None:
+        for ch in dflt:
+            if ch.tag == "default":
+                raise ValueError("nested <default> classes are outside the hot-path subset")
+            defaults[ch.tag] = dict(ch.attrib)
+    opt = root.find("option")
+    dt = float(opt.get("timestep", 0.002)) if opt is not None else 0.002
+    gravity = _floats(opt.get("gravity") if opt is not None else None, 3, np.array([0, 0, -9.81]))
+    custom = dict(_CUSTOM_DEFAULTS)
+    cst = root.find("custom")
+    if cst is not None:
+        for n in cst.findall("numeric"):
+            custom[n.get("name")] = float(n.get("data").split()[0])
+
+    world = root.find("worldbody")
+    floor = None
+    for g in world.findall("geom"):
+        a = _merged(defaults, "geom", g)
+        if a.get("type") == "plane":
+            fr = _floats(a.get("friction"), None, np.array([1.0, 0.005, 0.0001]))
+            floor = dict(contype=int(a.get("contype", 1)), conaffinity=int(a.get("conaffinity", 1)),
+                         friction=float(fr[0]))
+    top = _Body("world", np.zeros(3), np.array([1.0, 0, 0, 0]))
+    for bel in world.findall("body"):
+        top.children.append(_parse_body(bel, defaults, angle_scale))
+    _fuse(top)
+
+    # ---- flatten depth-first: one link per body -----------------------------------------------------
+    links: List[dict] = []
+
+    def visit(b: _Body, parent: int):
+        if drop_link_suffix and b.name.endswith(drop_link_suffix):
+            return
+        idx = len(links)
+        links.append(dict(body=b, parent=parent))
+        for c in b.children:
+            visit(c, idx)
+
+    for c in top.children:
+        visit(c, -1)
+    L = len(links)
+    if L > MAX_LINKS:
+        raise ValueError(f"{L} links > MBD_MAX_LINKS={MAX_LINKS}")
+
+    F: Dict[str, np.ndarray] = {}
+    z = lambda *s, dt_=np.float32: np.zeros(s, dt_)
+    F.update(parent=z(L, dt_=np.int32), n_rot=z(L, dt_=np.int32), n_slide=z(L, dt_=np.int32),
+             q_idx=z(L, dt_=np.int32), qd_idx=z(L, dt_=np.int32), inv_mass=z(L),
+             inv_inertia=z(L, 6), com=z(L, 3), ap_pos=z(L, 3), ap_rot=z(L, 4), ac_pos=z(L, 3),
+             ac_rot=z(L, 4), ang_damp=z(L), vel_damp=z(L), rot_lo=z(L, 3), rot_hi=z(L, 3),
+             rot_stiff=z(L, 3), rot_damp=z(L, 3), rot_sign=z(L, 3), slide_axis=z(L, 3, 3),
+             link_pos=z(L, 3), link_rot=z(L, 4), joint_pos=z(L, 3), rot_axis=z(L, 3, 3),
+             slide_axis_body=z(L, 3, 3))
+    F["ap_rot"][:, 0] = 1
+    F["ac_rot"][:, 0] = 1
+    F["link_rot"][:, 0] = 1
+    F["rot_sign"][:] = 1
+    init_q: List[float] = []
+    joint_slot: Dict[str, tuple] = {}
+    com64 = np.zeros((L, 3))
+    col_link: List[int] = []
+    col_pos: List[np.ndarray] = []
+    col_rad: List[float] = []
+    friction = floor["friction"] if floor else 1.0
+    iso = True
+    nq = nqd = 0
+    for l, ent in enumerate(links):
+        b: _Body = ent["body"]
+        F["parent"][l] = ent["parent"]
+        # ---- inertia from geoms -------------------------------------------------------------------
+        if not b.geoms:
+            raise ValueError(f"body {b.name!r} has no geoms: inertiafromgeom needs at least one")
+        ms, cs, Is = [], [], []
+        for g in b.geoms:
+            m_g, I_g = g.mass_inertia()
+            ms.append(m_g); cs.append(g.pos); Is.append(I_g)
+        mass = float(sum(ms))
+        com = sum(m_g * c for m_g, c in zip(ms, cs)) / mass
+        I = np.zeros((3, 3))
+        for m_g, c, I_g in zip(ms, cs, Is):
+            d = c - com
+            I += I_g + m_g * (np.dot(d, d) * np.eye(3) - np.outer(d, d))
+        com64[l] = com
+        lam, V = np.linalg.eigh(I)
+        lam_s = lam ** (1.0 - custom["spring_inertia_scale"])
+        Iinv = V @ np.diag(1.0 / lam_s) @ V.T
+        F["inv_mass"][l] = 1.0 / (mass ** (1.0 - custom["spring_mass_scale"]))
+        F["inv_inertia"][l] = [Iinv[0, 0], Iinv[1, 1], Iinv[2, 2], Iinv[0, 1], Iinv[0, 2], Iinv[1, 2]]
+        if not (np.allclose(Iinv, Iinv[0, 0] * np.eye(3), rtol=1e-6, atol=1e-9)):
+            iso = False
+        F["com"][l] = com
+        ent["mass"], ent["inertia"] = mass, I
+        # ---- joints ---------------------------------------------------------------------------------
+        kinds = [j.get("type", "hinge") for j in b.joints]
+        F["q_idx"][l], F["qd_idx"][l] = nq, nqd
+        F["ang_damp"][l] = custom["constraint_ang_damping"]
+        F["vel_damp"][l] = custom["constraint_vel_damping"]
+        if kinds == ["free"]:
+            F["n_rot"][l] = -1
+            if ent["parent"] != -1:
+                raise ValueError("free joint below the root")
+            init_q += list(b.pos) + list(b.quat)
+            nq += 7; nqd += 6
+            # free links carry no link transform (q holds the world pose)
+            F["link_pos"][l] = 0
+            continue
+        if "free" in kinds or "ball" in kinds:
+            raise ValueError(f"body {b.name!r}: joint mix {kinds} is outside the hot-path subset")
+        slides = [j for j in b.joints if j.get("type", "hinge") == "slide"]
+        hinges = [j for j in b.joints if j.get("type", "hinge") == "hinge"]
+        if b.joints[: len(slides)] != slides:
+            raise ValueError(f"body {b.name!r}: slide joints must precede hinge joints")
+        if len(slides) > 3 or len(hinges) > 3:
+            raise ValueError(f"body {b.name!r}: more than 3 dofs of one kind")
+        F["n_rot"][l], F["n_slide"][l] = len(hinges), len(slides)
+        F["link_pos"][l], F["link_rot"][l] = b.pos, b.quat
+        anchor = _floats((hinges or slides)[0].get("pos"), 3, np.zeros(3))
+        for j in hinges:
+            if not np.allclose(_floats(j.get("pos"), 3, np.zeros(3)), anchor):
+                raise ValueError(f"body {b.name!r}: hinge joints of one link must share their anchor")
+        F["joint_pos"][l] = anchor
+        axes = [(_floats(j.get("axis"), 3, np.array([0, 0, 1.0]))) for j in hinges]
+        axes = [a / np.linalg.norm(a) for a in axes]
+        sign3 = 1.0
+        if len(axes) == 0:
+            Rj = np.eye(3)
+        elif len(axes) == 1:
+            Rj = _q2mat(_from_to([1.0, 0, 0], axes[0]))
+        else:
+            if abs(np.dot(axes[0], axes[1])) > 1e-6:
+                raise ValueError(f"body {b.name!r}: hinge axes must be orthogonal")
+            e3 = np.cross(axes[0], axes[1])
+            if len(axes) == 3:
+                d3 = float(np.dot(e3, axes[2]))
+                if abs(abs(d3) - 1) > 1e-6:
+                    raise ValueError(f"body {b.name!r}: third hinge axis must be +-(a1 x a2)")
+                sign3 = 1.0 if d3 > 0 else -1.0
+            Rj = np.stack([axes[0], axes[1], e3], axis=1)
+        qj = _mat2q(Rj)
+        for k, (j, a) in enumerate(zip(hinges, axes)):
+            F["rot_axis"][l, k] = a
+            s = sign3 if k == 2 else 1.0
+            F["rot_sign"][l, k] = s
+            limited = j.get("limited")
+            has_range = "range" in j
+            lim = (limited == "true") if limited in ("true", "false") else has_range
+            if lim and has_range:
+                lo, hi = _floats(j["range"], 2) * angle_scale
+                lo, hi = (lo, hi) if s > 0 else (-hi, -lo)
+            else:
+                lo, hi = -_BIG, _BIG
+            F["rot_lo"][l, k], F["rot_hi"][l, k] = lo, hi
+            F["rot_stiff"][l, k] = float(j.get("stiffness", 0.0))
+            F["rot_damp"][l, k] = float(j.get("damping", 0.0))
+            joint_slot[j.get("name", f"{b.name}_h{k}")] = (l, k, s)
+        for k, j in enumerate(slides):
+            a = _floats(j.get("axis"), 3, np.array([0, 0, 1.0]))
+            a = a / np.linalg.norm(a)
+            F["slide_axis_body"][l, k] = a
+            F["slide_axis"][l, k] = Rj.T @ a
+            joint_slot[j.get("name", f"{b.name}_s{k}")] = (l, 3 + k, 1.0)
+        p = ent["parent"]
+        pcom = com64[p] if p >= 0 else np.zeros(3)
+        F["ap_pos"][l] = b.pos + _rot(anchor, b.quat) - pcom
+        F["ap_rot"][l] = _qmul(b.quat, qj)
+        F["ac_pos"][l] = anchor - com
+        F["ac_rot"][l] = qj
+        init_q += [0.0] * (len(slides) + len(hinges))
+        nq += len(slides) + len(hinges); nqd += len(slides) + len(hinges)
+        # ---- colliders (vs the floor plane) -------------------------------------------------------
+    for l, ent in enumerate(links):
+        for g in ent["body"].geoms:
+            if floor is None:
+                continue
+            if (g.contype & floor["conaffinity"]) | (floor["contype"] & g.conaffinity):
+                for pos, rad in g.sphere_points():
+                    col_link.append(l); col_pos.append(pos - com64[l]); col_rad.append(rad)
+                friction = max(friction, g.friction)
+    if len(col_link) > MAX_COL:
+        raise ValueError(f"{len(col_link)} colliders > MBD_MAX_COL={MAX_COL}")
+    if nq > MAX_Q:
+        raise ValueError(f"n_q {nq} > MBD_MAX_Q")
+
+    # ---- actuators ----------------------------------------------------------------------------------
+    act_link, act_slot, act_gear, act_lo, act_hi, act_names = [], [], [], [], [], []
+    act = root.find("actuator")
+    if act is not None:
+        for mtr in act:
+            if mtr.tag != "motor":
+                raise ValueError(f"actuator <{mtr.tag}> is outside the hot-path subset (motor only)")
+            a = _merged(defaults, "motor", mtr)
+            l, slot, s = joint_slot[a["joint"]]
+            gear = float(a.get("gear", "1").split()[0])
+            limited = a.get("ctrllimited", "auto")
+            if limited == "true" or (limited == "auto" and "ctrlrange" in a):
+                lo, hi = _floats(a["ctrlrange"], 2)
+            else:
+                lo, hi = -_BIG, _BIG
+            act_link.append(l); act_slot.append(slot); act_gear.append(gear * s)
+            act_lo.append(lo); act_hi.append(hi); act_names.append(a.get("name", a["joint"]))
+    if len(act_link) > MAX_ACT:
+        raise ValueError("too many actuators")
+    names = [ent["body"].name for ent in links]
+    track = [names.index(n) for n in track_names]
+    if len(track) > MAX_TRACK:
+        raise ValueError("too many tracked links")
+
+    F.update(
+        n_links=L, n_q=nq, n_qd=nqd, n_act=len(act_link), n_col=len(col_link), n_track=len(track),
+        n_frames=int(n_frames), reward_kind=REWARD_KINDS.get(env_name, 0), iso_inertia=int(iso),
+        dt=np.float32(dt), vel_fac=np.float32(math.exp(custom["vel_damping"] * dt)),
+        ang_fac=np.float32(math.exp(custom["ang_damping"] * dt)),
+        joint_scale_pos=np.float32(custom["joint_scale_pos"]),
+        joint_scale_ang=np.float32(custom["joint_scale_ang"]),
+        collide_scale=np.float32(custom["collide_scale"]), friction=np.float32(friction),
+        elasticity=np.float32(custom["elasticity"]), gravity=np.asarray(gravity, np.float32),
+        reset_noise=np.float32(reset_noise),
+        reward_params=np.asarray(list(reward_params) + [0.0] * (8 - len(reward_params)), np.float32),
+        act_link=np.asarray(act_link, np.int32), act_slot=np.asarray(act_slot, np.int32),
+        act_gear=np.asarray(act_gear, np.float32), act_lo=np.asarray(act_lo, np.float32),
+        act_hi=np.asarray(act_hi, np.float32),
+        col_link=np.asarray(col_link, np.int32),
+        col_pos=np.asarray(col_pos, np.float32).reshape(-1, 3),
+        col_radius=np.asarray(col_rad, np.float32),
+        init_q=np.asarray(init_q, np.float32), track_link=np.asarray(track, np.int32),
+    )
+    # python scalars for the scalar fields
+    for k in ("dt", "vel_fac", "ang_fac", "joint_scale_pos", "joint_scale_ang", "collide_scale",
+              "friction", "elasticity", "reset_noise"):
+        F[k] = float(F[k])
+    model = Model(F, names, act_names, env_name)
+    model.masses = np.array([ent["mass"] for ent in links])      # diagnostics / tests only
+    model.inertias = np.stack([ent["inertia"] for ent in links])
+    return model

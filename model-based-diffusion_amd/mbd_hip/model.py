@@ -1,0 +1,128 @@
+"""ctypes mirror of ``mbd_model_t`` (include/mbd_hip.h) + JSON (de)serialisation of compiled models.
+
+The compiled model is what ``brax.io.mjcf.load`` hands the reference's envs as ``sys``
+(mbd/envs/humanoidrun.py:15, hopper.py:14, humanoidtrack.py:16), flattened to one POD struct that the
+HIP rollout kernel reads from constant memory.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import json
+from typing import Any, Dict, List
+
+import numpy as np
+
+MAX_LINKS = 16
+MAX_Q = 40
+MAX_ACT = 24
+MAX_COL = 8
+MAX_TRACK = 8
+LINK_STATE = 13
+
+REWARD_KINDS = {"humanoidrun": 0, "hopper": 1, "halfcheetah": 2, "humanoidtrack": 3}
+
+_L, _A, _K, _T = MAX_LINKS, MAX_ACT, MAX_COL, MAX_TRACK
+_f, _i = C.c_float, C.c_int32
+
+
+class MbdModel(C.Structure):
+    """Field order and sizes must match include/mbd_hip.h exactly (checked by tests/test_capi.py)."""
+
+    _fields_ = [
+        ("n_links", _i), ("n_q", _i), ("n_qd", _i), ("n_act", _i), ("n_col", _i), ("n_track", _i),
+        ("n_frames", _i), ("reward_kind", _i), ("iso_inertia", _i), ("reserved_i", _i * 3),
+        ("dt", _f), ("vel_fac", _f), ("ang_fac", _f), ("joint_scale_pos", _f), ("joint_scale_ang", _f),
+        ("collide_scale", _f), ("friction", _f), ("elasticity", _f), ("gravity", _f * 3),
+        ("reset_noise", _f), ("reward_params", _f * 8),
+        ("parent", _i * _L), ("n_rot", _i * _L), ("n_slide", _i * _L), ("q_idx", _i * _L),
+        ("qd_idx", _i * _L),
+        ("inv_mass", _f * _L), ("inv_inertia", (_f * 6) * _L), ("com", (_f * 3) * _L),
+        ("ap_pos", (_f * 3) * _L), ("ap_rot", (_f * 4) * _L), ("ac_pos", (_f * 3) * _L),
+        ("ac_rot", (_f * 4) * _L),
+        ("ang_damp", _f * _L), ("vel_damp", _f * _L),
+        ("rot_lo", (_f * 3) * _L), ("rot_hi", (_f * 3) * _L), ("rot_stiff", (_f * 3) * _L),
+        ("rot_damp", (_f * 3) * _L), ("rot_sign", (_f * 3) * _L),
+        ("slide_axis", ((_f * 3) * 3) * _L),
+        ("act_link", _i * _A), ("act_slot", _i * _A), ("act_gear", _f * _A), ("act_lo", _f * _A),
+        ("act_hi", _f * _A),
+        ("col_link", _i * _K), ("col_pos", (_f * 3) * _K), ("col_radius", _f * _K),
+        ("link_pos", (_f * 3) * _L), ("link_rot", (_f * 4) * _L), ("joint_pos", (_f * 3) * _L),
+        ("rot_axis", ((_f * 3) * 3) * _L), ("slide_axis_body", ((_f * 3) * 3) * _L),
+        ("init_q", _f * MAX_Q),
+        ("track_link", _i * _T),
+    ]
+
+
+_SCALARS = ["n_links", "n_q", "n_qd", "n_act", "n_col", "n_track", "n_frames", "reward_kind",
+            "iso_inertia", "dt", "vel_fac", "ang_fac", "joint_scale_pos", "joint_scale_ang",
+            "collide_scale", "friction", "elasticity", "reset_noise"]
+_ARRAYS = [n for n, _t in MbdModel._fields_ if n not in _SCALARS and n != "reserved_i"]
+
+
+class Model:
+    """A compiled model: plain numpy arrays keyed like the struct fields, plus names for the shim."""
+
+    def __init__(self, fields: Dict[str, Any], link_names: List[str], actuator_names: List[str],
+                 env_name: str = ""):
+        self.fields = fields
+        self.link_names = list(link_names)
+        self.actuator_names = list(actuator_names)
+        self.env_name = env_name
+
+    # -- sizes the reference reads off `sys` --------------------------------------------------------
+    def q_size(self) -> int:
+        return int(self.fields["n_q"])
+
+    def qd_size(self) -> int:
+        return int(self.fields["n_qd"])
+
+    def act_size(self) -> int:
+        return int(self.fields["n_act"])
+
+    @property
+    def n_links(self) -> int:
+        return int(self.fields["n_links"])
+
+    @property
+    def init_q(self) -> np.ndarray:
+        return np.asarray(self.fields["init_q"], np.float32)[: self.q_size()].copy()
+
+    def to_struct(self) -> MbdModel:
+        s = MbdModel()
+        for name in _SCALARS:
+            setattr(s, name, self.fields[name])
+        for name in _ARRAYS:
+            ctype_arr = getattr(s, name)
+            dst = np.ctypeslib.as_array(ctype_arr)
+            src = np.asarray(self.fields[name])
+            view = dst[tuple(slice(0, n) for n in src.shape)] if src.ndim else dst
+            view[...] = src
+        return s
+
+    def to_json(self) -> str:
+        out = {"env_name": self.env_name, "link_names": self.link_names,
+               "actuator_names": self.actuator_names, "fields": {}}
+        for k, v in self.fields.items():
+            a = np.asarray(v)
+            if a.ndim == 0:
+                out["fields"][k] = a.item()
+            else:
+                # float32 values round-trip exactly through repr of the python float
+                out["fields"][k] = a.astype(np.float64 if a.dtype.kind == "f" else np.int64).tolist()
+        return json.dumps(out, indent=1)
+
+    @staticmethod
+    def from_json(text: str) -> "Model":
+        d = json.loads(text)
+        fields: Dict[str, Any] = {}
+        ftypes = dict((n, t) for n, t in MbdModel._fields_)
+        for k, v in d["fields"].items():
+            if isinstance(v, list):
+                base = ftypes[k]
+                while hasattr(base, "_type_") and not isinstance(base._type_, str):
+                    base = base._type_
+                kind = np.int32 if base._type_ == "i" else np.float32
+                fields[k] = np.asarray(v, dtype=kind)
+            else:
+                fields[k] = v
+        return Model(fields, d["link_names"], d["actuator_names"], d.get("env_name", ""))

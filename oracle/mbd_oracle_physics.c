@@ -1,0 +1,565 @@
+/*
+ * mbd_oracle_physics.c — TEST INFRASTRUCTURE ONLY (CPU oracle).  Never linked into or imported by the
+ * product; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load it.
+ *
+ * CPU restatement of what the reference calls through `PipelineEnv.pipeline_step(..)` with
+ * backend="positional" (call sites: mbd/envs/humanoidrun.py:17,29,36; hopper.py:18,30,40;
+ * humanoidtrack.py:46,54,65) plus the env wrappers' rewards (humanoidrun.py:46-51, hopper.py:57-65,
+ * humanoidtrack.py:87-96) and `rollout_us` (mbd/utils.py:14-20).
+ *
+ * PARITY UNPINNED.  The arithmetic lives in Brax (third-party; not vendored, not pinned and not even
+ * declared by the reference's setup.py:8-24; absent from this container, as are jax and mujoco), so
+ * this file restates the PUBLISHED algorithm the positional backend implements — maximal-coordinate
+ * extended position-based dynamics, Müller et al. 2020, "Detailed Rigid Body Simulation with Extended
+ * Position Based Dynamics" — in the stage order of brax/positional/pipeline.py::step as recalled in
+ * SURVEY.md App. C:
+ *     actuator.to_tau -> joints.acceleration_update (+gravity) -> integrator.integrate_xdd ->
+ *     joints.position_update -> geometry.contact + collisions.resolve_position ->
+ *     integrator.project_xd -> collisions.resolve_velocity
+ * It is the SPECIFICATION the HIP kernels are tested against (teacher-forced, per diffusion step);
+ * it is not bit-compatible with Brax and no claim of that is made.  tools/dump_golden.py produces
+ * real Brax vectors when run under a jax+brax install; tests consume them if present.
+ *
+ * NUMERICAL CONTRACT: all arithmetic goes through oracle/spec_math.h (explicit fma order, exact div /
+ * sqrt, polynomial atan2) and the per-link code is written in the same masked, lane-uniform form the
+ * HIP kernel uses (a link = a lane; parent data fetched, children's contributions added in increasing
+ * child index), so the kernel reproduces these results BIT FOR BIT.  See DESIGN.md §Numerics.
+ *
+ * Build:  -DORC_REAL=float (default, matches the reference's f32) or -DORC_REAL=double (used by the
+ * tests to measure how much f32 round-off is amplified over a rollout).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "../include/mbd_hip.h"
+#include "spec_math.h"
+
+#define ORC_API __attribute__((visibility("default")))
+
+typedef struct { real p[3]; real r[4]; } xf_t;
+typedef struct { real v[3]; real w[3]; } mo_t;
+
+typedef struct {
+  real inv_mass;
+  real ib[6];    /* body-frame inverse inertia xx yy zz xy xz yz */
+  const real* r; /* orientation */
+  int iso;       /* model-wide: inverse inertia is ib[0] * identity */
+  int world;     /* the static world: everything is zero */
+} inert_t;
+
+/* world-frame inverse inertia applied to v: R * Ib * R^T v  (iso: ib0 * v) */
+static inline void iinv_apply(const inert_t* in, const real v[3], real o[3]) {
+  if (in->world) { sp_set3(o, 0, 0, 0); return; }
+  if (in->iso) { sp_scale3(v, in->ib[0], o); return; }
+  real l[3], m[3];
+  sp_irot(v, in->r, l);
+  m[0] = sp_fma(in->ib[4], l[2], sp_fma(in->ib[3], l[1], in->ib[0] * l[0]));
+  m[1] = sp_fma(in->ib[5], l[2], sp_fma(in->ib[1], l[1], in->ib[3] * l[0]));
+  m[2] = sp_fma(in->ib[2], l[2], sp_fma(in->ib[5], l[1], in->ib[4] * l[0]));
+  sp_rot(m, in->r, o);
+}
+
+/* joint frames of link l given parent pose P and child pose C (kinematics.world_to_joint) */
+typedef struct {
+  real ap[3], ac[3]; /* anchor world positions on parent / child                                   */
+  real aprot[4], acrot[4];
+  real Xp[3], Yp[3], Zp[3], Xc[3], Yc[3], Zc[3];
+  real ang[3];       /* joint-frame Euler angles x, y', z''                                        */
+  real ax[3][3];     /* gimbal axes in the world frame: Xp, line of nodes, Zc                      */
+} jf_t;
+
+static void joint_frames(const mbd_model_t* m, int l, const xf_t* P, const xf_t* C, jf_t* f) {
+  real appos[3] = {m->ap_pos[l][0], m->ap_pos[l][1], m->ap_pos[l][2]};
+  real acpos[3] = {m->ac_pos[l][0], m->ac_pos[l][1], m->ac_pos[l][2]};
+  real aprot[4] = {m->ap_rot[l][0], m->ap_rot[l][1], m->ap_rot[l][2], m->ap_rot[l][3]};
+  real acrot[4] = {m->ac_rot[l][0], m->ac_rot[l][1], m->ac_rot[l][2], m->ac_rot[l][3]};
+  real t[3];
+  sp_rot(appos, P->r, t); sp_add3(P->p, t, f->ap);
+  sp_rot(acpos, C->r, t); sp_add3(C->p, t, f->ac);
+  sp_qmul(P->r, aprot, f->aprot);
+  sp_qmul(C->r, acrot, f->acrot);
+  sp_qaxes(f->aprot, f->Xp, f->Yp, f->Zp);
+  sp_qaxes(f->acrot, f->Xc, f->Yc, f->Zc);
+  /* R_rel = Rx(a) Ry(b) Rz(c), columns = child axes in the parent joint frame */
+  f->ang[0] = sp_atan2(-sp_dot3(f->Zc, f->Yp), sp_dot3(f->Zc, f->Zp));
+  f->ang[1] = sp_asin(sp_clip(sp_dot3(f->Zc, f->Xp), R(-1), R(1)));
+  f->ang[2] = sp_atan2(-sp_dot3(f->Yc, f->Xp), sp_dot3(f->Xc, f->Xp));
+  sp_copy3(f->Xp, f->ax[0]);
+  sp_copy3(f->Zc, f->ax[2]);
+  real n[3];
+  sp_cross3(f->Zc, f->Xp, n);
+  real inv = R(1) / (sp_sqrt(sp_dot3(n, n)) + R(1e-10));
+  sp_scale3(n, inv, f->ax[1]);
+}
+
+/* one angular positional correction: rotate child by +e, parent by -e, split by angular inverse
+ * masses. e: rotation-vector error (world). accumulates into dth_c / dth_p. */
+static void ang_correct(const real e[3], const inert_t* ip, const inert_t* ic, real scale, real dth_p[3],
+                        real dth_c[3]) {
+  real th = sp_sqrt(sp_dot3(e, e));
+  real inv = R(1) / (th + R(1e-10));
+  real n[3], inp[3], inc[3];
+  sp_scale3(e, inv, n);
+  iinv_apply(ip, n, inp);
+  iinv_apply(ic, n, inc);
+  real wp = sp_dot3(n, inp), wc = sp_dot3(n, inc);
+  real dlam = (th / (wp + wc + R(1e-10))) * scale;
+  sp_axpy3(dlam, inc, dth_c);
+  sp_axpy3(-dlam, inp, dth_p);
+}
+
+typedef struct {
+  int active;
+  real pos[3]; /* world contact point */
+  real dlam;   /* normal lambda of the positional solve */
+} contact_t;
+
+/* ------------------------------------------------------------------------------------------------ */
+/* one physics substep (brax/positional/pipeline.py::step)                                           */
+/* ------------------------------------------------------------------------------------------------ */
+static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot /* [L][3] */,
+                    const real* tau_slide /* [L][3] */) {
+  const int L = m->n_links;
+  const real dt = R(m->dt);
+  const real inv_dt = R(1) / dt;
+  static const xf_t WORLD_X = {{0, 0, 0}, {1, 0, 0, 0}};
+  static const mo_t WORLD_XD = {{0, 0, 0}, {0, 0, 0}};
+  inert_t in[MBD_MAX_LINKS + 1];
+  for (int l = 0; l < L; ++l) {
+    in[l].inv_mass = R(m->inv_mass[l]);
+    for (int k = 0; k < 6; ++k) in[l].ib[k] = R(m->inv_inertia[l][k]);
+    in[l].r = x[l].r;
+    in[l].iso = m->iso_inertia;
+    in[l].world = 0;
+  }
+  inert_t* world_in = &in[MBD_MAX_LINKS];
+  memset(world_in, 0, sizeof(*world_in));
+  world_in->r = WORLD_X.r; world_in->world = 1;
+
+  /* ---- (1) joints.acceleration_update: actuator torque, joint spring/damping, constraint damping */
+  real fc_v[MBD_MAX_LINKS][3], fc_w[MBD_MAX_LINKS][3]; /* acceleration of the child from its own joint */
+  real fp_v[MBD_MAX_LINKS][3], fp_w[MBD_MAX_LINKS][3]; /* acceleration of the parent from joint l     */
+  memset(fc_v, 0, sizeof(fc_v)); memset(fc_w, 0, sizeof(fc_w));
+  memset(fp_v, 0, sizeof(fp_v)); memset(fp_w, 0, sizeof(fp_w));
+  for (int l = 0; l < L; ++l) {
+    if (m->n_rot[l] < 0) continue; /* free joint: no joint forces */
+    const int p = m->parent[l];
+    const xf_t* P = p >= 0 ? &x[p] : &WORLD_X;
+    const mo_t* Pd = p >= 0 ? &xd[p] : &WORLD_XD;
+    const inert_t* ip = p >= 0 ? &in[p] : world_in;
+    jf_t f;
+    joint_frames(m, l, P, &x[l], &f);
+    real rc[3], rp[3], t[3], vc[3], vp[3], rel_v[3], rel_w[3];
+    sp_sub3(f.ac, x[l].p, rc); sp_sub3(f.ap, P->p, rp);
+    sp_cross3(xd[l].w, rc, t); sp_add3(xd[l].v, t, vc);
+    sp_cross3(Pd->w, rp, t); sp_add3(Pd->v, t, vp);
+    sp_sub3(vc, vp, rel_v); sp_sub3(xd[l].w, Pd->w, rel_w);
+    real T[3] = {0, 0, 0}, F[3] = {0, 0, 0};
+    for (int k = 0; k < 3; ++k) {
+      real qdk = sp_dot3(rel_w, f.ax[k]);
+      real fk = sp_fma(-R(m->rot_stiff[l][k]), f.ang[k], sp_fma(-R(m->rot_damp[l][k]), qdk, tau_rot[l * 3 + k]));
+      if (k >= m->n_rot[l]) fk = R(0);
+      sp_axpy3(fk, f.ax[k], T);
+    }
+    for (int k = 0; k < m->n_slide[l]; ++k) {
+      real s[3], sa[3] = {m->slide_axis[l][k][0], m->slide_axis[l][k][1], m->slide_axis[l][k][2]};
+      sp_rot(sa, f.aprot, s);
+      sp_axpy3(tau_slide[l * 3 + k], s, F);
+      sp_axpy3(-sp_dot3(rel_v, s), s, rel_v); /* free direction: not damped */
+    }
+    sp_axpy3(-R(m->ang_damp[l]), rel_w, T);
+    sp_axpy3(-R(m->vel_damp[l]), rel_v, F);
+    /* child: +F at anchor, +T ; parent: -F at anchor, -T */
+    real mom[3], tot[3];
+    sp_scale3(F, in[l].inv_mass, fc_v[l]);
+    sp_cross3(rc, F, mom); sp_add3(T, mom, tot); iinv_apply(&in[l], tot, fc_w[l]);
+    sp_scale3(F, -ip->inv_mass, fp_v[l]);
+    sp_cross3(rp, F, mom); sp_add3(T, mom, tot); iinv_apply(ip, tot, t); sp_scale3(t, R(-1), fp_w[l]);
+  }
+  /* ---- (2) integrator.integrate_xdd: damp, accelerate (+gravity), integrate pose */
+  xf_t x_prev[MBD_MAX_LINKS];
+  for (int l = 0; l < L; ++l) {
+    real av[3], aw[3];
+    sp_copy3(fc_v[l], av); sp_copy3(fc_w[l], aw);
+    for (int c = l + 1; c < L; ++c)
+      if (m->parent[c] == l) { sp_add3(av, fp_v[c], av); sp_add3(aw, fp_w[c], aw); }
+    for (int i = 0; i < 3; ++i) {
+      xd[l].v[i] = sp_fma(av[i] + R(m->gravity[i]), dt, R(m->vel_fac) * xd[l].v[i]);
+      xd[l].w[i] = sp_fma(aw[i], dt, R(m->ang_fac) * xd[l].w[i]);
+    }
+    x_prev[l] = x[l];
+    for (int i = 0; i < 3; ++i) x[l].p[i] = sp_fma(xd[l].v[i], dt, x[l].p[i]);
+    real th[3];
+    sp_scale3(xd[l].w, dt, th);
+    sp_qrotvec(x[l].r, th);
+  }
+  /* ---- (3) joints.position_update (Jacobi: every joint sees the same post-integration poses) */
+  real dc_p[MBD_MAX_LINKS][3], dc_th[MBD_MAX_LINKS][3], dp_p[MBD_MAX_LINKS][3], dp_th[MBD_MAX_LINKS][3];
+  memset(dc_p, 0, sizeof(dc_p)); memset(dc_th, 0, sizeof(dc_th));
+  memset(dp_p, 0, sizeof(dp_p)); memset(dp_th, 0, sizeof(dp_th));
+  for (int l = 0; l < L; ++l) {
+    if (m->n_rot[l] < 0) continue;
+    const int p = m->parent[l];
+    const xf_t* P = p >= 0 ? &x[p] : &WORLD_X;
+    const inert_t* ip = p >= 0 ? &in[p] : world_in;
+    const inert_t* ic = &in[l];
+    jf_t f;
+    joint_frames(m, l, P, &x[l], &f);
+    /* translational: pull the child anchor onto the parent anchor (free along slide axes) */
+    real d[3], rc[3], rp[3];
+    sp_sub3(f.ap, f.ac, d);
+    for (int k = 0; k < m->n_slide[l]; ++k) {
+      real s[3], sa[3] = {m->slide_axis[l][k][0], m->slide_axis[l][k][1], m->slide_axis[l][k][2]};
+      sp_rot(sa, f.aprot, s);
+      sp_axpy3(-sp_dot3(d, s), s, d);
+    }
+    sp_sub3(f.ac, x[l].p, rc); sp_sub3(f.ap, P->p, rp);
+    real c = sp_sqrt(sp_dot3(d, d));
+    real inv = R(1) / (c + R(1e-10));
+    real n[3], cp[3], cc[3], icp[3], icc[3];
+    sp_scale3(d, inv, n);
+    sp_cross3(rp, n, cp); sp_cross3(rc, n, cc);
+    iinv_apply(ip, cp, icp); iinv_apply(ic, cc, icc);
+    real wp = ip->inv_mass + sp_dot3(cp, icp), wc = ic->inv_mass + sp_dot3(cc, icc);
+    real dlam = (c / (wp + wc)) * R(m->joint_scale_pos);
+    real Pimp[3], mom[3], t[3];
+    sp_scale3(n, dlam, Pimp);
+    sp_scale3(Pimp, ic->inv_mass, dc_p[l]);
+    sp_cross3(rc, Pimp, mom); iinv_apply(ic, mom, dc_th[l]);
+    sp_scale3(Pimp, -ip->inv_mass, dp_p[l]);
+    sp_cross3(rp, Pimp, mom); iinv_apply(ip, mom, t); sp_scale3(t, R(-1), dp_th[l]);
+    /* angular alignment by joint type */
+    real e[3] = {0, 0, 0};
+    const int nr = m->n_rot[l];
+    if (nr == 0) {
+      real qc[4] = {f.acrot[0], -f.acrot[1], -f.acrot[2], -f.acrot[3]}, qe[4];
+      sp_qmul(f.aprot, qc, qe);
+      real s = qe[0] < R(0) ? R(-2) : R(2);
+      sp_set3(e, s * qe[1], s * qe[2], s * qe[3]);
+    } else {
+      const real* A = nr == 1 ? f.Xc : f.Xp;
+      const real* B = nr == 1 ? f.Xp : f.Yc;
+      real sc = nr == 1 ? R(1) : (nr == 2 ? sp_dot3(f.Xp, f.Yc) : R(0));
+      real cr[3];
+      sp_cross3(A, B, cr);
+      sp_scale3(cr, sc, e);
+    }
+    ang_correct(e, ip, ic, R(m->joint_scale_ang), dp_th[l], dc_th[l]);
+    /* joint limits on the Euler angles */
+    for (int k = 0; k < 3; ++k) {
+      real a = f.ang[k], lo = R(m->rot_lo[l][k]), hi = R(m->rot_hi[l][k]);
+      real viol = a < lo ? a - lo : (a > hi ? a - hi : R(0));
+      if (k >= nr) viol = R(0);
+      real el[3];
+      sp_scale3(f.ax[k], -viol, el);
+      ang_correct(el, ip, ic, R(m->joint_scale_ang), dp_th[l], dc_th[l]);
+    }
+  }
+  for (int l = 0; l < L; ++l) {
+    real dp[3], dth[3];
+    sp_copy3(dc_p[l], dp); sp_copy3(dc_th[l], dth);
+    for (int c = l + 1; c < L; ++c)
+      if (m->parent[c] == l) { sp_add3(dp, dp_p[c], dp); sp_add3(dth, dp_th[c], dth); }
+    sp_add3(x[l].p, dp, x[l].p);
+    sp_qrotvec(x[l].r, dth);
+  }
+  /* ---- (4) geometry.contact (sphere-plane) + collisions.resolve_position */
+  contact_t con[MBD_MAX_COL];
+  real cd_p[MBD_MAX_LINKS][3], cd_th[MBD_MAX_LINKS][3];
+  int has_col[MBD_MAX_LINKS];
+  memset(cd_p, 0, sizeof(cd_p)); memset(cd_th, 0, sizeof(cd_th)); memset(has_col, 0, sizeof(has_col));
+  const real mu = R(m->friction);
+  const real nrm[3] = {0, 0, 1};
+  for (int k = 0; k < m->n_col; ++k) {
+    const int l = m->col_link[k];
+    has_col[l] = 1;
+    real cl[3] = {m->col_pos[k][0], m->col_pos[k][1], m->col_pos[k][2]}, t[3], ctr[3];
+    sp_rot(cl, x[l].r, t); sp_add3(x[l].p, t, ctr);
+    const real rad = R(m->col_radius[k]);
+    real pen = rad - ctr[2];
+    con[k].active = pen > R(0);
+    con[k].dlam = 0;
+    if (!con[k].active) continue;
+    sp_set3(con[k].pos, ctr[0], ctr[1], ctr[2] - sp_fma(R(-0.5), pen, rad));
+    real rc[3], cn[3], icn[3];
+    sp_sub3(con[k].pos, x[l].p, rc);
+    sp_cross3(rc, nrm, cn); iinv_apply(&in[l], cn, icn);
+    real w = in[l].inv_mass + sp_dot3(cn, icn);
+    real dlam = (pen / w) * R(m->collide_scale);
+    con[k].dlam = dlam;
+    real Pimp[3], mom[3];
+    sp_scale3(nrm, dlam, Pimp);
+    /* static friction: undo the tangential motion of the contact point over this substep if the
+     * required tangential lambda stays inside the friction cone */
+    real rl[3], pprev[3], dx[3];
+    sp_irot(rc, x[l].r, rl); sp_rot(rl, x_prev[l].r, t); sp_add3(x_prev[l].p, t, pprev);
+    sp_sub3(con[k].pos, pprev, dx);
+    sp_axpy3(-sp_dot3(dx, nrm), nrm, dx);
+    real ct = sp_sqrt(sp_dot3(dx, dx));
+    real inv = R(1) / (ct + R(1e-10));
+    real nt[3], cnt[3], icnt[3];
+    sp_scale3(dx, inv, nt);
+    sp_cross3(rc, nt, cnt); iinv_apply(&in[l], cnt, icnt);
+    real wt = in[l].inv_mass + sp_dot3(cnt, icnt);
+    real dlamt = -(ct / wt);
+    if (sp_abs(dlamt) < mu * dlam) sp_axpy3(dlamt, nt, Pimp);
+    sp_axpy3(in[l].inv_mass, Pimp, cd_p[l]);
+    sp_cross3(rc, Pimp, mom); iinv_apply(&in[l], mom, t); sp_add3(cd_th[l], t, cd_th[l]);
+  }
+  for (int l = 0; l < L; ++l) {
+    if (!has_col[l]) continue;
+    sp_add3(x[l].p, cd_p[l], x[l].p);
+    sp_qrotvec(x[l].r, cd_th[l]);
+  }
+  /* ---- (5) integrator.project_xd: velocities from the position change */
+  mo_t xd_prev[MBD_MAX_LINKS];
+  for (int l = 0; l < L; ++l) {
+    xd_prev[l] = xd[l];
+    for (int i = 0; i < 3; ++i) xd[l].v[i] = (x[l].p[i] - x_prev[l].p[i]) * inv_dt;
+    real qc[4] = {x_prev[l].r[0], -x_prev[l].r[1], -x_prev[l].r[2], -x_prev[l].r[3]}, dq[4];
+    sp_qmul(x[l].r, qc, dq);
+    real s = (dq[0] < R(0) ? R(-2) : R(2)) * inv_dt;
+    for (int i = 0; i < 3; ++i) xd[l].w[i] = dq[1 + i] * s;
+  }
+  /* ---- (6) collisions.resolve_velocity: restitution + dynamic friction at active contacts */
+  for (int k = 0; k < m->n_col; ++k) {
+    if (!con[k].active) continue;
+    const int l = m->col_link[k];
+    real rc[3], t[3], vpt[3], vprev[3];
+    sp_sub3(con[k].pos, x[l].p, rc);
+    sp_cross3(xd[l].w, rc, t); sp_add3(xd[l].v, t, vpt);
+    sp_cross3(xd_prev[l].w, rc, t); sp_add3(xd_prev[l].v, t, vprev);
+    real vn = sp_dot3(vpt, nrm), vn_prev = sp_dot3(vprev, nrm);
+    real vt[3];
+    sp_copy3(vpt, vt);
+    sp_axpy3(-vn, nrm, vt);
+    real vtn = sp_sqrt(sp_dot3(vt, vt));
+    real inv = R(1) / (vtn + R(1e-10));
+    real dir[3], cn[3], icn[3], cdv[3], icd[3];
+    sp_scale3(vt, inv, dir);
+    sp_cross3(rc, nrm, cn); iinv_apply(&in[l], cn, icn);
+    sp_cross3(rc, dir, cdv); iinv_apply(&in[l], cdv, icd);
+    real wn = in[l].inv_mass + sp_dot3(cn, icn), wt = in[l].inv_mass + sp_dot3(cdv, icd);
+    real rest = -R(m->elasticity) * vn_prev;
+    real dvn = sp_min(rest, R(0)) - vn;
+    real jt_max = (mu * con[k].dlam) * inv_dt; /* friction impulse bound mu * lambda_n / h */
+    real dvt = sp_min(jt_max * wt, vtn);
+    real jn = dvn / wn, jt = -(dvt / wt);
+    real Pimp[3];
+    sp_scale3(nrm, jn, Pimp);
+    sp_axpy3(jt, dir, Pimp);
+    sp_axpy3(in[l].inv_mass, Pimp, xd[l].v);
+    real mom[3];
+    sp_cross3(rc, Pimp, mom); iinv_apply(&in[l], mom, t); sp_add3(xd[l].w, t, xd[l].w);
+  }
+}
+
+/* ---- state <-> float buffers -------------------------------------------------------------------- */
+static void load_state(const float* s, int L, xf_t* x, mo_t* xd) {
+  for (int l = 0; l < L; ++l) {
+    const float* a = s + l * MBD_LINK_STATE;
+    for (int i = 0; i < 3; ++i) { x[l].p[i] = a[i]; xd[l].v[i] = a[7 + i]; xd[l].w[i] = a[10 + i]; }
+    for (int i = 0; i < 4; ++i) x[l].r[i] = a[3 + i];
+  }
+}
+static void store_state(float* s, int L, const xf_t* x, const mo_t* xd) {
+  for (int l = 0; l < L; ++l) {
+    float* a = s + l * MBD_LINK_STATE;
+    for (int i = 0; i < 3; ++i) { a[i] = (float)x[l].p[i]; a[7 + i] = (float)xd[l].v[i]; a[10 + i] = (float)xd[l].w[i]; }
+    for (int i = 0; i < 4; ++i) a[3 + i] = (float)x[l].r[i];
+  }
+}
+/* world position of the link-frame origin: x.pos = x_i.pos - rotate(com, rot)  (com.to_world) */
+static void link_origin(const mbd_model_t* m, int l, const xf_t* x, real o[3]) {
+  real c[3] = {m->com[l][0], m->com[l][1], m->com[l][2]}, t[3];
+  sp_rot(c, x[l].r, t);
+  sp_sub3(x[l].p, t, o);
+}
+static void link_origin_vel(const mbd_model_t* m, int l, const xf_t* x, const mo_t* xd, real o[3]) {
+  real c[3] = {m->com[l][0], m->com[l][1], m->com[l][2]}, t[3], u[3];
+  sp_rot(c, x[l].r, t);
+  sp_cross3(xd[l].w, t, u);
+  sp_sub3(xd[l].v, u, o);
+}
+
+/* env.step for one environment: n_frames substeps with the action held, then the reward
+ * (PipelineEnv.pipeline_step + the env wrapper's _get_reward). returns the reward. */
+static real env_step(const mbd_model_t* m, xf_t* x, mo_t* xd, const float* action) {
+  const int L = m->n_links;
+  real tau_rot[MBD_MAX_LINKS * 3], tau_slide[MBD_MAX_LINKS * 3];
+  memset(tau_rot, 0, sizeof(tau_rot)); memset(tau_slide, 0, sizeof(tau_slide));
+  /* actuator.to_tau: clip to ctrlrange, times gear, scatter */
+  for (int a = 0; a < m->n_act; ++a) {
+    real u = sp_clip(R(action[a]), R(m->act_lo[a]), R(m->act_hi[a])) * R(m->act_gear[a]);
+    int l = m->act_link[a], s = m->act_slot[a];
+    if (s < 3) tau_rot[l * 3 + s] += u; else tau_slide[l * 3 + s - 3] += u;
+  }
+  real o0[3], v0[3];
+  link_origin(m, 0, x, o0);
+  link_origin_vel(m, 0, x, xd, v0);
+  for (int f = 0; f < m->n_frames; ++f) substep(m, x, xd, tau_rot, tau_slide);
+  real o1[3];
+  link_origin(m, 0, x, o1);
+  (void)L;
+  switch (m->reward_kind) {
+    case MBD_REW_HUMANOIDRUN: /* humanoidrun.py:46-51 */
+      return o1[0] * R(1) - sp_clip(sp_abs(o1[2] - R(1.3)), R(-1), R(1)) * R(1) - sp_abs(o1[1]) * R(0.1);
+    case MBD_REW_HOPPER: /* hopper.py:57-65 */
+      return o1[0] - sp_clip(sp_abs(o1[2] - R(1.0)), R(-1), R(1)) * R(0.5);
+    case MBD_REW_HALFCHEETAH: { /* brax half_cheetah: forward velocity - 0.1*|a|^2 */
+      real ctrl = 0;
+      for (int a = 0; a < m->n_act; ++a) ctrl += R(action[a]) * R(action[a]);
+      real dtc = R(m->dt) * (real)m->n_frames;
+      return R(m->reward_params[0]) * ((o1[0] - o0[0]) / dtc) - R(m->reward_params[1]) * ctrl;
+    }
+    case MBD_REW_HUMANOIDTRACK: /* humanoidtrack.py:87-96: from the INCOMING state */
+      return R(1) + (-sp_abs(v0[0] - R(1.6)) - sp_abs(o0[2] - R(1.3)) - sp_abs(o0[1]) * R(0.1));
+    default: return 0;
+  }
+}
+
+ORC_API float orc_env_step(const mbd_model_t* m, const float* state_in, const float* action,
+                           float* state_out) {
+  xf_t x[MBD_MAX_LINKS]; mo_t xd[MBD_MAX_LINKS];
+  load_state(state_in, m->n_links, x, xd);
+  real r = env_step(m, x, xd, action);
+  store_state(state_out, m->n_links, x, xd);
+  return (float)r;
+}
+
+/* a single physics substep with explicit generalized forces — used by the invariants tests */
+ORC_API void orc_substep(const mbd_model_t* m, const float* state_in, const float* action,
+                         float* state_out) {
+  xf_t x[MBD_MAX_LINKS]; mo_t xd[MBD_MAX_LINKS];
+  load_state(state_in, m->n_links, x, xd);
+  real tau_rot[MBD_MAX_LINKS * 3], tau_slide[MBD_MAX_LINKS * 3];
+  memset(tau_rot, 0, sizeof(tau_rot)); memset(tau_slide, 0, sizeof(tau_slide));
+  for (int a = 0; a < m->n_act; ++a) {
+    real u = sp_clip(R(action[a]), R(m->act_lo[a]), R(m->act_hi[a])) * R(m->act_gear[a]);
+    int l = m->act_link[a], s = m->act_slot[a];
+    if (s < 3) tau_rot[l * 3 + s] += u; else tau_slide[l * 3 + s - 3] += u;
+  }
+  substep(m, x, xd, tau_rot, tau_slide);
+  store_state(state_out, m->n_links, x, xd);
+}
+
+/* jax.vmap(rollout_us, in_axes=(None, 0)) (mbd_planner.py:109; utils.py:14-20): the reward and the
+ * tracked link positions AFTER every control step. Single-threaded (cores = 1) unless built with
+ * -fopenmp, in which case candidates are distributed over threads. */
+ORC_API void orc_rollout(const mbd_model_t* m, const float* state0, const float* us /* [B][H][Nu] */,
+                         int B, int H, float* rewss /* [B][H] */, float* xpos /* [B][H][K][3] or NULL */,
+                         float* state_final /* [B][state] or NULL */) {
+  const int L = m->n_links, Nu = m->n_act, K = m->n_track;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+  for (int b = 0; b < B; ++b) {
+    xf_t x[MBD_MAX_LINKS]; mo_t xd[MBD_MAX_LINKS];
+    load_state(state0, L, x, xd);
+    for (int t = 0; t < H; ++t) {
+      real r = env_step(m, x, xd, &us[((size_t)b * H + t) * Nu]);
+      rewss[(size_t)b * H + t] = (float)r;
+      if (xpos)
+        for (int k = 0; k < K; ++k) {
+          real o[3];
+          link_origin(m, m->track_link[k], x, o);
+          for (int i = 0; i < 3; ++i) xpos[(((size_t)b * H + t) * K + k) * 3 + i] = (float)o[i];
+        }
+    }
+    if (state_final) store_state(state_final + (size_t)b * L * MBD_LINK_STATE, L, x, xd);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* reset: kinematics.forward + com.from_world  (pipeline_init; humanoidrun.py:29, hopper.py:30)      */
+/* q [n_q], qd [n_qd] -> state [L][13]                                                               */
+/* ------------------------------------------------------------------------------------------------ */
+ORC_API void orc_forward(const mbd_model_t* m, const float* q, const float* qd, float* state) {
+  const int L = m->n_links;
+  xf_t X[MBD_MAX_LINKS];   /* link frames */
+  real V[MBD_MAX_LINKS][3], W[MBD_MAX_LINKS][3]; /* velocity of the link origin, angular velocity */
+  xf_t x[MBD_MAX_LINKS]; mo_t xd[MBD_MAX_LINKS];
+  for (int l = 0; l < L; ++l) {
+    const int p = m->parent[l];
+    xf_t P = {{0, 0, 0}, {1, 0, 0, 0}};
+    real Pv[3] = {0, 0, 0}, Pw[3] = {0, 0, 0};
+    if (p >= 0) { P = X[p]; memcpy(Pv, V[p], sizeof(Pv)); memcpy(Pw, W[p], sizeof(Pw)); }
+    const float* ql = q + m->q_idx[l];
+    const float* qdl = qd + m->qd_idx[l];
+    if (m->n_rot[l] < 0) { /* free joint: q = pos, quat ; qd = vel, ang */
+      for (int i = 0; i < 3; ++i) { X[l].p[i] = ql[i]; V[l][i] = qdl[i]; W[l][i] = qdl[3 + i]; }
+      for (int i = 0; i < 4; ++i) X[l].r[i] = ql[3 + i];
+      sp_qnormalize(X[l].r); /* deviation candidate: brax may leave the reset quaternion un-normalised */
+    } else {
+      real jpos[3] = {0, 0, 0}, jrot[4] = {1, 0, 0, 0}, sv[3] = {0, 0, 0}, wrel[3] = {0, 0, 0};
+      const int ns = m->n_slide[l], nr = m->n_rot[l];
+      for (int k = 0; k < ns; ++k) {
+        real a[3] = {m->slide_axis_body[l][k][0], m->slide_axis_body[l][k][1], m->slide_axis_body[l][k][2]};
+        sp_axpy3(R(ql[k]), a, jpos);
+        sp_axpy3(R(qdl[k]), a, sv);
+      }
+      for (int k = 0; k < nr; ++k) {
+        real a[3] = {m->rot_axis[l][k][0], m->rot_axis[l][k][1], m->rot_axis[l][k][2]}, ac[3];
+        sp_rot(a, jrot, ac);
+        sp_axpy3(R(qdl[ns + k]), ac, wrel);
+        real h = R(0.5) * R(ql[ns + k]);
+        real s, c;
+        sp_sincos(h, &s, &c);
+        real qk[4] = {c, s * a[0], s * a[1], s * a[2]}, t[4];
+        sp_qmul(jrot, qk, t);
+        memcpy(jrot, t, sizeof(t));
+      }
+      real jp[3] = {m->joint_pos[l][0], m->joint_pos[l][1], m->joint_pos[l][2]}, t[3];
+      sp_rot(jp, jrot, t);
+      for (int i = 0; i < 3; ++i) jpos[i] += jp[i] - t[i];
+      real lp[3] = {m->link_pos[l][0], m->link_pos[l][1], m->link_pos[l][2]};
+      real lr[4] = {m->link_rot[l][0], m->link_rot[l][1], m->link_rot[l][2], m->link_rot[l][3]};
+      real lpos[3], lrot[4];
+      sp_rot(jpos, lr, t); sp_add3(lp, t, lpos);
+      sp_qmul(lr, jrot, lrot);
+      sp_rot(lpos, P.r, t); sp_add3(P.p, t, X[l].p);
+      sp_qmul(P.r, lrot, X[l].r);
+      real u[3], A[3], rA[3], vA[3];
+      sp_rot(wrel, lr, t); sp_rot(t, P.r, u); sp_add3(Pw, u, W[l]);
+      sp_rot(jp, X[l].r, rA); sp_add3(X[l].p, rA, A);
+      sp_sub3(A, P.p, t); sp_cross3(Pw, t, u); sp_add3(Pv, u, vA);
+      sp_rot(sv, lr, t); sp_rot(t, P.r, u); sp_add3(vA, u, vA);
+      sp_cross3(W[l], rA, u); sp_sub3(vA, u, V[l]);
+    }
+    /* com.from_world */
+    real c[3] = {m->com[l][0], m->com[l][1], m->com[l][2]}, rc[3], u[3];
+    sp_rot(c, X[l].r, rc);
+    sp_add3(X[l].p, rc, x[l].p);
+    memcpy(x[l].r, X[l].r, sizeof(x[l].r));
+    sp_cross3(W[l], rc, u); sp_add3(V[l], u, xd[l].v);
+    memcpy(xd[l].w, W[l], sizeof(xd[l].w));
+  }
+  store_state(state, L, x, xd);
+}
+
+/* world positions of all link origins [L][3] (x.pos) and joint angles, for tests and viewers */
+ORC_API void orc_link_positions(const mbd_model_t* m, const float* state, float* xpos) {
+  xf_t x[MBD_MAX_LINKS]; mo_t xd[MBD_MAX_LINKS];
+  load_state(state, m->n_links, x, xd);
+  for (int l = 0; l < m->n_links; ++l) {
+    real o[3];
+    link_origin(m, l, x, o);
+    for (int i = 0; i < 3; ++i) xpos[l * 3 + i] = (float)o[i];
+  }
+}
+ORC_API void orc_joint_angles(const mbd_model_t* m, const float* state, float* ang /* [L][3] */) {
+  static const xf_t WORLD_X = {{0, 0, 0}, {1, 0, 0, 0}};
+  xf_t x[MBD_MAX_LINKS]; mo_t xd[MBD_MAX_LINKS];
+  load_state(state, m->n_links, x, xd);
+  for (int l = 0; l < m->n_links; ++l) {
+    for (int i = 0; i < 3; ++i) ang[l * 3 + i] = 0;
+    if (m->n_rot[l] < 0) continue;
+    jf_t f;
+    joint_frames(m, l, m->parent[l] >= 0 ? &x[m->parent[l]] : &WORLD_X, &x[l], &f);
+    for (int i = 0; i < 3; ++i) ang[l * 3 + i] = (float)f.ang[i];
+  }
+}
+ORC_API int orc_real_bytes(void) { return (int)sizeof(real); }
+ORC_API int orc_model_bytes(void) { return (int)sizeof(mbd_model_t); }
