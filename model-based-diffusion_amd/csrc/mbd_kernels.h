@@ -1,0 +1,698 @@
+// mbd_kernels.h — hand-written HIP kernels (gfx950 / CDNA4, wave64) for the reverse-diffusion hot path
+// of mbd/planners/mbd_planner.py:97-135:
+//
+//   sample_kernel        A1  eps -> Y0s = clip(eps*sigma_i + Ybar_i, -1, 1)        (:103-106)
+//   rollout_kernel       A2/A3  vmap(rollout_us) of the positional rigid-body step (:109, utils.py:14-20)
+//   car2d_rollout_kernel A2/A3  the same for the in-tree car2d env                  (car2d.py:77-93)
+//   logpd_*_kernel       A5  eval_xref_logpd                                        (:118)
+//   score_kernel         A4-A6  standardise, demo blend, softmax                    (:110-127)
+//   wmean_kernel         A7-A8  einsum("n,nij->ij") + score update                  (:128-133)
+//
+// Layout of the rollout kernel (the one that matters): ONE LINK PER LANE.  A candidate occupies LPS
+// consecutive lanes of a wavefront (LPS = 16 for the 11-link humanoid, 8 for the 7-link cheetah, 4 for
+// the hopper), 64/LPS candidates per wavefront, one wavefront per workgroup, so N=1024 humanoid
+// candidates are 256 single-wave workgroups = one per CU, spread evenly over the 8 XCDs.  The 13-float
+// link state, its previous pose and ~90 per-link model constants stay in VGPRs for the whole
+// H x n_frames rollout; a parent's state and the children's constraint contributions move between
+// lanes with ds_bpermute (no LDS allocation, no barriers); HBM is touched only for the action fetch
+// (prefetched one control step ahead) and the reward store.  All arithmetic follows mbd_math.h.
+#pragma once
+
+#include "../../include/mbd_hip.h"
+#include "mbd_math.h"
+
+namespace mbd {
+
+constexpr int kMaxChildren = 4;
+
+struct RolloutParams {
+  const mbd_model_t* model;  // device copy of the compiled model
+  const float* state0;       // [L][13]
+  const float* us;           // [B][H][Nu]
+  float* rewss;              // [B][H] or nullptr
+  float* rews;               // [B] or nullptr: mean over H
+  float* xpos;               // [B][H][K][3] or nullptr
+  float* state_final;        // [B][L][13] or nullptr
+  int B, H;
+};
+
+__device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
+__device__ __forceinline__ v3 shfl3(v3 v, int src) { return v3{shfl(v.x, src), shfl(v.y, src), shfl(v.z, src)}; }
+__device__ __forceinline__ q4 shfl4(q4 q, int src) {
+  return q4{shfl(q.w, src), shfl(q.x, src), shfl(q.y, src), shfl(q.z, src)};
+}
+
+template <bool ISO>
+struct Inert {
+  float inv_mass;
+  float ib[ISO ? 1 : 6];
+};
+// world-frame inverse inertia applied to v
+template <bool ISO>
+__device__ __forceinline__ v3 iinv(const Inert<ISO>& in, q4 r, v3 v) {
+  if constexpr (ISO) {
+    return scale(v, in.ib[0]);
+  } else {
+    v3 l = irot(v, r);
+    v3 m;
+    m.x = ffma(in.ib[4], l.z, ffma(in.ib[3], l.y, in.ib[0] * l.x));
+    m.y = ffma(in.ib[5], l.z, ffma(in.ib[1], l.y, in.ib[3] * l.x));
+    m.z = ffma(in.ib[2], l.z, ffma(in.ib[5], l.y, in.ib[4] * l.x));
+    return rot(m, r);
+  }
+}
+
+struct JointFrames {
+  v3 ap, ac;
+  q4 aprot;
+  v3 Xp, Xc, Yc, Zc, ax1;
+  float ang[3];
+};
+
+struct JointConst {
+  v3 ap_pos, ac_pos;
+  q4 ap_rot, ac_rot;
+};
+
+__device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp, q4 Pr, v3 Cp, q4 Cr) {
+  JointFrames f;
+  f.ap = add(Pp, rot(jc.ap_pos, Pr));
+  f.ac = add(Cp, rot(jc.ac_pos, Cr));
+  f.aprot = qmul(Pr, jc.ap_rot);
+  q4 acrot = qmul(Cr, jc.ac_rot);
+  axes3 A = qaxes(f.aprot), C = qaxes(acrot);
+  f.Xp = A.X; f.Xc = C.X; f.Yc = C.Y; f.Zc = C.Z;
+  f.ang[0] = atan2_(-dot(C.Z, A.Y), dot(C.Z, A.Z));
+  f.ang[1] = asin_(fclip(dot(C.Z, A.X), -1.0f, 1.0f));
+  f.ang[2] = atan2_(-dot(C.Y, A.X), dot(C.X, A.X));
+  v3 n = cross(C.Z, A.X);
+  float inv = 1.0f / (fsqrt(dot(n, n)) + 1e-10f);
+  f.ax1 = scale(n, inv);
+  return f;
+}
+
+template <bool ISO>
+__device__ __forceinline__ void ang_correct(v3 e, const Inert<ISO>& ip, q4 Pr, const Inert<ISO>& ic, q4 Cr,
+                                            float sc, v3& dth_p, v3& dth_c) {
+  float th = fsqrt(dot(e, e));
+  float inv = 1.0f / (th + 1e-10f);
+  v3 n = scale(e, inv);
+  v3 inp = iinv<ISO>(ip, Pr, n), inc = iinv<ISO>(ic, Cr, n);
+  float wp = dot(n, inp), wc = dot(n, inc);
+  float dlam = (th / (wp + wc + 1e-10f)) * sc;
+  dth_c = axpy(dlam, inc, dth_c);
+  dth_p = axpy(-dlam, inp, dth_p);
+}
+
+// LPS   lanes per candidate (power of two >= n_links)
+// ISO   model-wide isotropic inverse inertia (spring_inertia_scale = 1 models: the humanoid)
+// SLIDES any slide dof in the model (planar roots of hopper / halfcheetah)
+// MAXCH max children of any link; MAXCOL max sphere colliders on any link
+template <int LPS, bool ISO, bool SLIDES, int MAXCH, int MAXCOL>
+__global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
+  const mbd_model_t* __restrict__ M = P.model;
+  const int lane = threadIdx.x & 63;
+  const int base = lane & ~(LPS - 1);
+  const int l_raw = lane & (LPS - 1);
+  const int L = M->n_links;
+  const bool link_ok = l_raw < L;
+  const int l = link_ok ? l_raw : 0;
+  constexpr int SPW = 64 / LPS;
+  const int b_raw = blockIdx.x * SPW + lane / LPS;
+  const bool b_ok = b_raw < P.B;
+  const int b = b_ok ? b_raw : P.B - 1;
+  const int H = P.H, Nu = M->n_act, nfr = M->n_frames, K = M->n_track;
+
+  // ---- per-lane model constants -----------------------------------------------------------------------
+  const int parent = M->parent[l];
+  const int nr = M->n_rot[l];
+  const bool is_joint = link_ok && nr >= 0;
+  const int ns = SLIDES ? M->n_slide[l] : 0;
+  const int plane = parent >= 0 ? base + parent : lane;  // lane holding the parent (self if world)
+  const bool world_parent = parent < 0;
+  Inert<ISO> ic, ip;
+  ic.inv_mass = M->inv_mass[l];
+  ip.inv_mass = world_parent ? 0.0f : M->inv_mass[parent >= 0 ? parent : 0];
+#pragma unroll
+  for (int k = 0; k < (ISO ? 1 : 6); ++k) {
+    ic.ib[k] = M->inv_inertia[l][k];
+    ip.ib[k] = world_parent ? 0.0f : M->inv_inertia[parent >= 0 ? parent : 0][k];
+  }
+  JointConst jc;
+  jc.ap_pos = mk3(M->ap_pos[l][0], M->ap_pos[l][1], M->ap_pos[l][2]);
+  jc.ac_pos = mk3(M->ac_pos[l][0], M->ac_pos[l][1], M->ac_pos[l][2]);
+  jc.ap_rot = q4{M->ap_rot[l][0], M->ap_rot[l][1], M->ap_rot[l][2], M->ap_rot[l][3]};
+  jc.ac_rot = q4{M->ac_rot[l][0], M->ac_rot[l][1], M->ac_rot[l][2], M->ac_rot[l][3]};
+  const float ang_damp = M->ang_damp[l], vel_damp = M->vel_damp[l];
+  float lim_lo[3], lim_hi[3], stiff[3], damp[3];
+  v3 saxis[3];
+  int act_rot[3], act_sl[3];
+  float gear_rot[3], gear_sl[3], alo_rot[3], ahi_rot[3], alo_sl[3], ahi_sl[3];
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    lim_lo[k] = M->rot_lo[l][k]; lim_hi[k] = M->rot_hi[l][k];
+    stiff[k] = M->rot_stiff[l][k]; damp[k] = M->rot_damp[l][k];
+    saxis[k] = mk3(M->slide_axis[l][k][0], M->slide_axis[l][k][1], M->slide_axis[l][k][2]);
+    act_rot[k] = -1; act_sl[k] = -1;
+    gear_rot[k] = gear_sl[k] = 0.0f; alo_rot[k] = alo_sl[k] = 0.0f; ahi_rot[k] = ahi_sl[k] = 0.0f;
+  }
+  for (int a = 0; a < Nu; ++a) {
+    if (M->act_link[a] != l || !link_ok) continue;
+    const int s = M->act_slot[a];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      if (s == k) { act_rot[k] = a; gear_rot[k] = M->act_gear[a]; alo_rot[k] = M->act_lo[a]; ahi_rot[k] = M->act_hi[a]; }
+      if (s == 3 + k) { act_sl[k] = a; gear_sl[k] = M->act_gear[a]; alo_sl[k] = M->act_lo[a]; ahi_sl[k] = M->act_hi[a]; }
+    }
+  }
+  int child_lane[MAXCH];
+  {
+    int nc = 0;
+#pragma unroll
+    for (int c = 0; c < MAXCH; ++c) child_lane[c] = -1;
+    for (int c = l + 1; c < L; ++c)
+      if (M->parent[c] == l && link_ok) {
+#pragma unroll
+        for (int j = 0; j < MAXCH; ++j)
+          if (j == nc) child_lane[j] = base + c;
+        ++nc;
+      }
+  }
+  v3 col_pos[MAXCOL];
+  float col_rad[MAXCOL];
+  bool col_has[MAXCOL];
+  {
+    int nc = 0;
+#pragma unroll
+    for (int j = 0; j < MAXCOL; ++j) { col_has[j] = false; col_rad[j] = 0.0f; col_pos[j] = mk3(0, 0, 0); }
+    for (int k = 0; k < M->n_col; ++k)
+      if (M->col_link[k] == l && link_ok) {
+#pragma unroll
+        for (int j = 0; j < MAXCOL; ++j)
+          if (j == nc) {
+            col_has[j] = true; col_rad[j] = M->col_radius[k];
+            col_pos[j] = mk3(M->col_pos[k][0], M->col_pos[k][1], M->col_pos[k][2]);
+          }
+        ++nc;
+      }
+  }
+  bool any_col = false;
+#pragma unroll
+  for (int j = 0; j < MAXCOL; ++j) any_col = any_col || col_has[j];
+  int track_k = -1;
+  for (int k = 0; k < K; ++k)
+    if (M->track_link[k] == l && link_ok) track_k = k;
+  const v3 com = mk3(M->com[l][0], M->com[l][1], M->com[l][2]);
+  const float dt = M->dt, inv_dt = 1.0f / M->dt, vel_fac = M->vel_fac, ang_fac = M->ang_fac;
+  const float js_pos = M->joint_scale_pos, js_ang = M->joint_scale_ang, coll_scale = M->collide_scale;
+  const float mu = M->friction, elast = M->elasticity;
+  const v3 grav = mk3(M->gravity[0], M->gravity[1], M->gravity[2]);
+  const v3 nrm = mk3(0.0f, 0.0f, 1.0f);
+  const int rkind = M->reward_kind;
+  const float rp0 = M->reward_params[0], rp1 = M->reward_params[1];
+  const float dt_ctrl = M->dt * (float)nfr;
+
+  // ---- state -------------------------------------------------------------------------------------------
+  const float* s0 = P.state0 + l * MBD_LINK_STATE;
+  v3 p = mk3(s0[0], s0[1], s0[2]);
+  q4 r = q4{s0[3], s0[4], s0[5], s0[6]};
+  v3 v = mk3(s0[7], s0[8], s0[9]);
+  v3 w = mk3(s0[10], s0[11], s0[12]);
+  if (!link_ok) { p = mk3(0, 0, 0); r = q4{1, 0, 0, 0}; v = mk3(0, 0, 0); w = mk3(0, 0, 0); }
+
+  const float* u_row = P.us + (size_t)b * H * Nu;
+  float u_rot[3], u_sl[3];
+  auto load_actions = [&](int t) {
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      u_rot[k] = act_rot[k] >= 0 ? u_row[(size_t)t * Nu + act_rot[k]] : 0.0f;
+      if constexpr (SLIDES) u_sl[k] = act_sl[k] >= 0 ? u_row[(size_t)t * Nu + act_sl[k]] : 0.0f;
+    }
+  };
+  load_actions(0);
+  float rew_sum = 0.0f;
+
+  for (int t = 0; t < H; ++t) {
+    // actuator.to_tau: clip to ctrlrange, times gear
+    float tau[3], tau_sl[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+      tau[k] = fclip(u_rot[k], alo_rot[k], ahi_rot[k]) * gear_rot[k];
+      tau_sl[k] = SLIDES ? fclip(u_sl[k], alo_sl[k], ahi_sl[k]) * gear_sl[k] : 0.0f;
+    }
+    float ctrl_cost = 0.0f;
+    if (rkind == MBD_REW_HALFCHEETAH && l_raw == 0) {
+      for (int a = 0; a < Nu; ++a) {
+        float ua = u_row[(size_t)t * Nu + a];
+        ctrl_cost = ctrl_cost + ua * ua;
+      }
+    }
+    if (t + 1 < H) load_actions(t + 1);  // prefetch the next control step's actions
+    // link-frame origin before the step (rewards that look at the incoming state / finite differences)
+    const v3 o0 = sub(p, rot(com, r));
+    const v3 v0 = sub(v, cross(w, rot(com, r)));
+
+    for (int fr = 0; fr < nfr; ++fr) {
+      // ---- (1) joints.acceleration_update ----------------------------------------------------------
+      v3 Pp = shfl3(p, plane), Pv = shfl3(v, plane), Pw = shfl3(w, plane);
+      q4 Pr = shfl4(r, plane);
+      if (world_parent) { Pp = mk3(0, 0, 0); Pv = mk3(0, 0, 0); Pw = mk3(0, 0, 0); Pr = q4{1, 0, 0, 0}; }
+      v3 fc_v, fc_w, fp_v, fp_w;
+      {
+        JointFrames f = joint_frames(jc, Pp, Pr, p, r);
+        v3 rc = sub(f.ac, p), rp = sub(f.ap, Pp);
+        v3 vc = add(v, cross(w, rc)), vp = add(Pv, cross(Pw, rp));
+        v3 rel_v = sub(vc, vp), rel_w = sub(w, Pw);
+        v3 T = mk3(0, 0, 0), F = mk3(0, 0, 0);
+        const v3 axk[3] = {f.Xp, f.ax1, f.Zc};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float qdk = dot(rel_w, axk[k]);
+          float fk = ffma(-stiff[k], f.ang[k], ffma(-damp[k], qdk, tau[k]));
+          fk = k < nr ? fk : 0.0f;
+          T = axpy(fk, axk[k], T);
+        }
+        if constexpr (SLIDES) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            v3 s = rot(saxis[k], f.aprot);
+            F = axpy(k < ns ? tau_sl[k] : 0.0f, s, F);
+            float cf = k < ns ? -dot(rel_v, s) : 0.0f;
+            rel_v = axpy(cf, s, rel_v);
+          }
+        }
+        T = axpy(-ang_damp, rel_w, T);
+        F = axpy(-vel_damp, rel_v, F);
+        fc_v = scale(F, ic.inv_mass);
+        fc_w = iinv<ISO>(ic, r, add(T, cross(rc, F)));
+        fp_v = scale(F, -ip.inv_mass);
+        fp_w = scale(iinv<ISO>(ip, Pr, add(T, cross(rp, F))), -1.0f);
+        if (!is_joint) { fc_v = fc_w = fp_v = fp_w = mk3(0, 0, 0); }
+      }
+      // ---- (2) integrator.integrate_xdd -------------------------------------------------------------
+      v3 av = fc_v, aw = fc_w;
+#pragma unroll
+      for (int c = 0; c < MAXCH; ++c) {
+        const bool has = child_lane[c] >= 0;
+        const int src = has ? child_lane[c] : lane;
+        v3 cv = shfl3(fp_v, src), cw = shfl3(fp_w, src);
+        av = has ? add(av, cv) : av;
+        aw = has ? add(aw, cw) : aw;
+      }
+      v = mk3(ffma(av.x + grav.x, dt, vel_fac * v.x), ffma(av.y + grav.y, dt, vel_fac * v.y),
+              ffma(av.z + grav.z, dt, vel_fac * v.z));
+      w = mk3(ffma(aw.x, dt, ang_fac * w.x), ffma(aw.y, dt, ang_fac * w.y), ffma(aw.z, dt, ang_fac * w.z));
+      const v3 p_prev = p;
+      const q4 r_prev = r;
+      p = mk3(ffma(v.x, dt, p.x), ffma(v.y, dt, p.y), ffma(v.z, dt, p.z));
+      r = qrotvec(r, scale(w, dt));
+      // ---- (3) joints.position_update (Jacobi) ------------------------------------------------------
+      Pp = shfl3(p, plane);
+      Pr = shfl4(r, plane);
+      if (world_parent) { Pp = mk3(0, 0, 0); Pr = q4{1, 0, 0, 0}; }
+      v3 dc_p, dc_th, dp_p, dp_th;
+      {
+        JointFrames f = joint_frames(jc, Pp, Pr, p, r);
+        v3 d = sub(f.ap, f.ac);
+        if constexpr (SLIDES) {
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            v3 s = rot(saxis[k], f.aprot);
+            float cf = k < ns ? -dot(d, s) : 0.0f;
+            d = axpy(cf, s, d);
+          }
+        }
+        v3 rc = sub(f.ac, p), rp = sub(f.ap, Pp);
+        float c = fsqrt(dot(d, d));
+        float inv = 1.0f / (c + 1e-10f);
+        v3 n = scale(d, inv);
+        v3 cp = cross(rp, n), cc = cross(rc, n);
+        v3 icp = iinv<ISO>(ip, Pr, cp), icc = iinv<ISO>(ic, r, cc);
+        float wp = ip.inv_mass + dot(cp, icp), wc = ic.inv_mass + dot(cc, icc);
+        float dlam = (c / (wp + wc)) * js_pos;
+        v3 Pimp = scale(n, dlam);
+        dc_p = scale(Pimp, ic.inv_mass);
+        dc_th = iinv<ISO>(ic, r, cross(rc, Pimp));
+        dp_p = scale(Pimp, -ip.inv_mass);
+        dp_th = scale(iinv<ISO>(ip, Pr, cross(rp, Pimp)), -1.0f);
+        // angular alignment by joint type (1 hinge: Xc || Xp; 2 hinges: Yc _|_ Xp; 3: free)
+        v3 A = nr == 1 ? f.Xc : f.Xp;
+        v3 Bv = nr == 1 ? f.Xp : f.Yc;
+        float sc = nr == 1 ? 1.0f : (nr == 2 ? dot(f.Xp, f.Yc) : 0.0f);
+        v3 e = scale(cross(A, Bv), sc);
+        ang_correct<ISO>(e, ip, Pr, ic, r, js_ang, dp_th, dc_th);
+        const v3 axk[3] = {f.Xp, f.ax1, f.Zc};
+#pragma unroll
+        for (int k = 0; k < 3; ++k) {
+          float a = f.ang[k];
+          float viol = a < lim_lo[k] ? a - lim_lo[k] : (a > lim_hi[k] ? a - lim_hi[k] : 0.0f);
+          viol = k < nr ? viol : 0.0f;
+          ang_correct<ISO>(scale(axk[k], -viol), ip, Pr, ic, r, js_ang, dp_th, dc_th);
+        }
+        if (!is_joint) { dc_p = dc_th = dp_p = dp_th = mk3(0, 0, 0); }
+      }
+      {
+        v3 dp = dc_p, dth = dc_th;
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+          const bool has = child_lane[c] >= 0;
+          const int src = has ? child_lane[c] : lane;
+          v3 cp = shfl3(dp_p, src), cth = shfl3(dp_th, src);
+          dp = has ? add(dp, cp) : dp;
+          dth = has ? add(dth, cth) : dth;
+        }
+        p = add(p, dp);
+        r = qrotvec(r, dth);
+      }
+      // ---- (4) sphere-plane contacts + collisions.resolve_position ---------------------------------
+      v3 con_pos[MAXCOL];
+      float con_dlam[MAXCOL];
+      bool con_act[MAXCOL];
+      {
+        v3 cd_p = mk3(0, 0, 0), cd_th = mk3(0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < MAXCOL; ++j) {
+          v3 ctr = add(p, rot(col_pos[j], r));
+          float pen = col_rad[j] - ctr.z;
+          bool active = col_has[j] && pen > 0.0f;
+          v3 pos = mk3(ctr.x, ctr.y, ctr.z - ffma(-0.5f, pen, col_rad[j]));
+          v3 rc = sub(pos, p);
+          v3 cn = cross(rc, nrm);
+          v3 icn = iinv<ISO>(ic, r, cn);
+          float wn = ic.inv_mass + dot(cn, icn);
+          float dlam = (pen / wn) * coll_scale;
+          v3 Pimp = scale(nrm, dlam);
+          v3 rl = irot(rc, r);
+          v3 pprev = add(p_prev, rot(rl, r_prev));
+          v3 dx = sub(pos, pprev);
+          dx = axpy(-dot(dx, nrm), nrm, dx);
+          float ct = fsqrt(dot(dx, dx));
+          float inv = 1.0f / (ct + 1e-10f);
+          v3 nt = scale(dx, inv);
+          v3 cnt = cross(rc, nt);
+          v3 icnt = iinv<ISO>(ic, r, cnt);
+          float wt = ic.inv_mass + dot(cnt, icnt);
+          float dlamt = -(ct / wt);
+          Pimp = fabs_(dlamt) < mu * dlam ? axpy(dlamt, nt, Pimp) : Pimp;
+          v3 ncd_p = axpy(ic.inv_mass, Pimp, cd_p);
+          v3 ncd_th = add(cd_th, iinv<ISO>(ic, r, cross(rc, Pimp)));
+          cd_p = active ? ncd_p : cd_p;
+          cd_th = active ? ncd_th : cd_th;
+          con_pos[j] = pos; con_dlam[j] = dlam; con_act[j] = active;
+        }
+        v3 np = add(p, cd_p);
+        q4 nr_ = qrotvec(r, cd_th);
+        p = any_col ? np : p;
+        r = any_col ? nr_ : r;
+      }
+      // ---- (5) integrator.project_xd ------------------------------------------------------------------
+      const v3 v_old = v, w_old = w;
+      v = mk3((p.x - p_prev.x) * inv_dt, (p.y - p_prev.y) * inv_dt, (p.z - p_prev.z) * inv_dt);
+      {
+        q4 dq = qmul(r, conj(r_prev));
+        float s = (dq.w < 0.0f ? -2.0f : 2.0f) * inv_dt;
+        w = mk3(dq.x * s, dq.y * s, dq.z * s);
+      }
+      // ---- (6) collisions.resolve_velocity --------------------------------------------------------------
+#pragma unroll
+      for (int j = 0; j < MAXCOL; ++j) {
+        v3 rc = sub(con_pos[j], p);
+        v3 vpt = add(v, cross(w, rc));
+        v3 vprev = add(v_old, cross(w_old, rc));
+        float vn = dot(vpt, nrm), vn_prev = dot(vprev, nrm);
+        v3 vt = axpy(-vn, nrm, vpt);
+        float vtn = fsqrt(dot(vt, vt));
+        float inv = 1.0f / (vtn + 1e-10f);
+        v3 dir = scale(vt, inv);
+        v3 cn = cross(rc, nrm), cdv = cross(rc, dir);
+        v3 icn = iinv<ISO>(ic, r, cn), icd = iinv<ISO>(ic, r, cdv);
+        float wn = ic.inv_mass + dot(cn, icn), wt = ic.inv_mass + dot(cdv, icd);
+        float rest = -elast * vn_prev;
+        float dvn = fmin_(rest, 0.0f) - vn;
+        float jt_max = (mu * con_dlam[j]) * inv_dt;
+        float dvt = fmin_(jt_max * wt, vtn);
+        float jn = dvn / wn, jt = -(dvt / wt);
+        v3 Pimp = axpy(jt, dir, scale(nrm, jn));
+        v3 nv = axpy(ic.inv_mass, Pimp, v);
+        v3 nw = add(w, iinv<ISO>(ic, r, cross(rc, Pimp)));
+        v = con_act[j] ? nv : v;
+        w = con_act[j] ? nw : w;
+      }
+    }  // substeps
+
+    // ---- reward (env wrapper's _get_reward) and tracked positions ------------------------------------
+    const v3 o1 = sub(p, rot(com, r));
+    if (l_raw == 0) {
+      float rew;
+      if (rkind == MBD_REW_HUMANOIDRUN) {
+        rew = o1.x * 1.0f - fclip(fabs_(o1.z - 1.3f), -1.0f, 1.0f) * 1.0f - fabs_(o1.y) * 0.1f;
+      } else if (rkind == MBD_REW_HOPPER) {
+        rew = o1.x - fclip(fabs_(o1.z - 1.0f), -1.0f, 1.0f) * 0.5f;
+      } else if (rkind == MBD_REW_HALFCHEETAH) {
+        rew = rp0 * ((o1.x - o0.x) / dt_ctrl) - rp1 * ctrl_cost;
+      } else {
+        rew = 1.0f + (-fabs_(v0.x - 1.6f) - fabs_(o0.z - 1.3f) - fabs_(o0.y) * 0.1f);
+      }
+      rew_sum = rew_sum + rew;
+      if (b_ok && P.rewss) P.rewss[(size_t)b * H + t] = rew;
+    }
+    if (P.xpos && track_k >= 0 && b_ok) {
+      float* o = P.xpos + (((size_t)b * H + t) * K + track_k) * 3;
+      o[0] = o1.x; o[1] = o1.y; o[2] = o1.z;
+    }
+  }  // control steps
+  if (l_raw == 0 && b_ok && P.rews) P.rews[b] = rew_sum / (float)H;
+  if (P.state_final && link_ok && b_ok) {
+    float* o = P.state_final + ((size_t)b * L + l) * MBD_LINK_STATE;
+    o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = r.w; o[4] = r.x; o[5] = r.y; o[6] = r.z;
+    o[7] = v.x; o[8] = v.y; o[9] = v.z; o[10] = w.x; o[11] = w.y; o[12] = w.z;
+  }
+}
+
+// ---- car2d (mbd/envs/car2d.py): one candidate per lane -------------------------------------------------
+struct Car2dParams {
+  const float* q0;  // [3]
+  const float* us;  // [B][H][2]
+  float* rewss;     // [B][H] or nullptr
+  float* rews;      // [B] or nullptr
+  float* qs;        // [B][H][3] or nullptr
+  float* q_final;   // [B][3] or nullptr
+  int B, H;
+};
+
+__device__ __forceinline__ void car_dyn(const float x[3], float u0, float u1, float dx[3]) {
+  float sn, cs;
+  sincos_(x[2], &sn, &cs);
+  dx[0] = u1 * sn * 3.0f;
+  dx[1] = u1 * cs * 3.0f;
+  dx[2] = u0 * 3.14159274101257324f / 3.0f * 2.0f;
+}
+__device__ __forceinline__ float car_reward(const float q[3]) {
+  float dx = q[0] - 0.5f, dy = q[1] - 0.0f;
+  float d = fsqrt(dx * dx + dy * dy);
+  d = fclip(d, 0.0f, 0.2f);
+  float t = d / 0.2f;
+  return 1.0f - t * t;
+}
+
+__global__ __launch_bounds__(64) void car2d_rollout_kernel(Car2dParams P) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= P.B) return;
+  // obstacle centres (car2d.py:48-63): python float64 products cast to f32
+  const float cx[11] = {(float)(0.3 * -3), (float)(0.3 * -2), (float)(0.3 * -1), 0.0f, 0.0f, 0.0f, 0.0f,
+                        (float)(0.3 * -3), (float)(0.3 * -2), (float)(0.3 * -1), 0.0f};
+  const float cy[11] = {(float)(0.3 * 2), (float)(0.3 * 2), (float)(0.3 * 2), (float)(0.3 * 2),
+                        (float)(0.3 * 1), 0.0f, (float)(0.3 * -1), (float)(0.3 * -2), (float)(0.3 * -2),
+                        (float)(0.3 * -2), (float)(0.3 * -2)};
+  const float dt = (float)0.1, dt2 = (float)(0.1 / 2), dt6 = (float)(0.1 / 6);
+  float q[3] = {P.q0[0], P.q0[1], P.q0[2]};
+  float sum = 0.0f;
+  for (int t = 0; t < P.H; ++t) {
+    const float* u = P.us + ((size_t)b * P.H + t) * 2;
+    float a0 = fclip(u[0], -1.0f, 1.0f), a1 = fclip(u[1], -1.0f, 1.0f);
+    float k1[3], k2[3], k3[3], k4[3], x[3], qn[3];
+    car_dyn(q, a0, a1, k1);
+    for (int i = 0; i < 3; ++i) x[i] = q[i] + dt2 * k1[i];
+    car_dyn(x, a0, a1, k2);
+    for (int i = 0; i < 3; ++i) x[i] = q[i] + dt2 * k2[i];
+    car_dyn(x, a0, a1, k3);
+    for (int i = 0; i < 3; ++i) x[i] = q[i] + dt * k3[i];
+    car_dyn(x, a0, a1, k4);
+    for (int i = 0; i < 3; ++i) qn[i] = q[i] + dt6 * (k1[i] + 2.0f * k2[i] + 2.0f * k3[i] + k4[i]);
+    bool collide = false;
+    for (int i = 0; i < 11; ++i) {
+      float dx = qn[0] - cx[i], dy = qn[1] - cy[i];
+      collide = collide || (fsqrt(dx * dx + dy * dy) < 0.3f);
+    }
+    for (int i = 0; i < 3; ++i) q[i] = collide ? q[i] : qn[i];
+    float rew = car_reward(q);
+    sum = sum + rew;
+    if (P.rewss) P.rewss[(size_t)b * P.H + t] = rew;
+    if (P.qs) { float* o = P.qs + ((size_t)b * P.H + t) * 3; o[0] = q[0]; o[1] = q[1]; o[2] = q[2]; }
+  }
+  if (P.rews) P.rews[b] = sum / (float)P.H;
+  if (P.q_final) { P.q_final[b * 3] = q[0]; P.q_final[b * 3 + 1] = q[1]; P.q_final[b * 3 + 2] = q[2]; }
+}
+
+// ---- A1: sampling (mbd_planner.py:103-106) -------------------------------------------------------------
+// Y0s[n][e] for rows [row_begin, row_begin+rows) of the global [N][HNu] tensor. One thread per threefry
+// block: legacy layout pairs element j with j+half (both outputs used); partitionable: one element.
+__global__ __launch_bounds__(256) void sample_kernel(uint32_t k0, uint32_t k1, int impl, int N, int HNu,
+                                                      float sigma, const float* __restrict__ Ybar,
+                                                      float* __restrict__ Y0s) {
+  const uint64_t size = (uint64_t)N * (uint64_t)HNu;
+  const uint64_t half = (size + 1) / 2;
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (impl == 1) {
+    if (tid >= size) return;
+    uint32_t o0, o1;
+    threefry2x32(k0, k1, (uint32_t)(tid >> 32), (uint32_t)tid, o0, o1);
+    float eps = bits_to_normal(o0 ^ o1);
+    float y = eps * sigma + Ybar[tid % (uint64_t)HNu];
+    Y0s[tid] = fclip(y, -1.0f, 1.0f);
+    return;
+  }
+  if (tid >= half) return;
+  const uint64_t j1 = tid + half;
+  uint32_t o0, o1;
+  threefry2x32(k0, k1, (uint32_t)tid, j1 < size ? (uint32_t)j1 : 0u, o0, o1);
+  {
+    float y = bits_to_normal(o0) * sigma + Ybar[tid % (uint64_t)HNu];
+    Y0s[tid] = fclip(y, -1.0f, 1.0f);
+  }
+  if (j1 < size) {
+    float y = bits_to_normal(o1) * sigma + Ybar[j1 % (uint64_t)HNu];
+    Y0s[j1] = fclip(y, -1.0f, 1.0f);
+  }
+}
+
+// ---- A5: demo log-densities ------------------------------------------------------------------------------
+// HumanoidTrack.eval_xref_logpd (humanoidtrack.py:98-106): xpos [B][H][K][3], xref [K][H][3]
+__global__ __launch_bounds__(64) void logpd_track_kernel(const float* __restrict__ xpos,
+                                                         const float* __restrict__ xref, int B, int H, int K,
+                                                         float* __restrict__ lp) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  float acc = 0.0f;
+  for (int k = 0; k < K; ++k)
+    for (int t = 0; t < H; ++t) {
+      const float* a = xpos + (((size_t)b * H + t) * K + k) * 3;
+      const float* c = xref + ((size_t)k * H + t) * 3;
+      float ex = a[0] - c[0], ey = a[1] - c[1], ez = a[2] - c[2];
+      float d = fsqrt(ex * ex + ey * ey + ez * ez);
+      d = fclip(d, 0.0f, 0.5f);
+      float s = d / 0.5f;
+      acc = acc + s * s;
+    }
+  lp[b] = 0.0f - acc / (float)(H * K);
+}
+// Car2d.eval_xref_logpd (car2d.py:95-102): qs [B][H][3], xref [H][2]
+__global__ __launch_bounds__(64) void logpd_car2d_kernel(const float* __restrict__ qs,
+                                                         const float* __restrict__ xref, int B, int H,
+                                                         float* __restrict__ lp) {
+  const int b = blockIdx.x * 64 + threadIdx.x;
+  if (b >= B) return;
+  float acc = 0.0f;
+  for (int t = 0; t < H; ++t) {
+    const float* a = qs + ((size_t)b * H + t) * 3;
+    float ex = a[0] - xref[2 * t], ey = a[1] - xref[2 * t + 1];
+    float d = fsqrt(ex * ex + ey * ey);
+    d = fclip(d, 0.0f, 0.5f);
+    float s = d / 0.5f;
+    acc = acc + s * s;
+  }
+  lp[b] = 0.0f - acc / (float)H;
+}
+
+// ---- A4-A6: standardise, demo blend, softmax -> weights[N] (mbd_planner.py:110-127) -------------------
+// ONE wavefront. The canonical reduction order of the numerical contract: lane j accumulates the
+// elements i = j, j+64, ... in increasing i, then a xor-butterfly over the 64 lanes.
+__device__ __forceinline__ float wave_sum(float x) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) x = x + __shfl_xor(x, off, 64);
+  return x;
+}
+__device__ __forceinline__ float wave_max(float x) {
+#pragma unroll
+  for (int off = 32; off >= 1; off >>= 1) x = fmax_(x, __shfl_xor(x, off, 64));
+  return x;
+}
+
+__global__ __launch_bounds__(64) void score_kernel(const float* __restrict__ rews,
+                                                   const float* __restrict__ lp_demo, int N, float rew_xref,
+                                                   float temp, float* __restrict__ weights,
+                                                   float* __restrict__ rew_mean_out) {
+  extern __shared__ __attribute__((aligned(16))) float lg[];  // logp0 [N]
+  const int lane = threadIdx.x;
+  float part = 0.0f;
+  for (int i = lane; i < N; i += 64) part = part + rews[i];
+  const float rew_mean = wave_sum(part) / (float)N;
+  part = 0.0f;
+  for (int i = lane; i < N; i += 64) {
+    float d = rews[i] - rew_mean;
+    part = ffma(d, d, part);
+  }
+  float rew_std = fsqrt(wave_sum(part) / (float)N);
+  rew_std = rew_std < 1e-4f ? 1.0f : rew_std;
+  for (int i = lane; i < N; i += 64) lg[i] = ((rews[i] - rew_mean) / rew_std) / temp;
+  if (lp_demo) {
+    float mx = -__builtin_inff();
+    for (int i = lane; i < N; i += 64) mx = fmax_(mx, lp_demo[i]);
+    mx = wave_max(mx);
+    part = 0.0f;
+    for (int i = lane; i < N; i += 64) {
+      float lpd = ((((lp_demo[i] - mx) + rew_xref) - rew_mean) / rew_std) / temp;
+      float v = lpd > lg[i] ? lpd : lg[i];
+      lg[i] = v;
+      part = part + v;
+    }
+    const float m = wave_sum(part) / (float)N;
+    part = 0.0f;
+    for (int i = lane; i < N; i += 64) {
+      float d = lg[i] - m;
+      part = ffma(d, d, part);
+    }
+    const float sd = fsqrt(wave_sum(part) / (float)N);
+    for (int i = lane; i < N; i += 64) lg[i] = ((lg[i] - m) / sd) / temp;
+  }
+  float mx = -__builtin_inff();
+  for (int i = lane; i < N; i += 64) mx = fmax_(mx, lg[i]);
+  mx = wave_max(mx);
+  part = 0.0f;
+  for (int i = lane; i < N; i += 64) {
+    float e = exp_(lg[i] - mx);
+    lg[i] = e;
+    part = part + e;
+  }
+  const float den = wave_sum(part);
+  for (int i = lane; i < N; i += 64) weights[i] = lg[i] / den;
+  if (lane == 0) *rew_mean_out = rew_mean;
+}
+
+// ---- A7-A8: weighted mean + score update (mbd_planner.py:128-133) ---------------------------------------
+// one thread per output element e of [H][Nu]; sequential fma over n (coalesced across e)
+__global__ __launch_bounds__(64) void wmean_kernel(const float* __restrict__ weights,
+                                                   const float* __restrict__ Y0s, int N, int HNu,
+                                                   const float* __restrict__ Ybar_i, float alpha_i,
+                                                   float alpha_bar_i, float alpha_bar_im1, int literal,
+                                                   float* __restrict__ Ybar_im1) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= HNu) return;
+  float acc = 0.0f;
+#pragma unroll 8
+  for (int n = 0; n < N; ++n) acc = ffma(weights[n], Y0s[(size_t)n * HNu + e], acc);
+  float out = acc;
+  if (literal) {
+    const float sab = fsqrt(alpha_bar_i);
+    float Yi = Ybar_i[e] * sab;
+    float t1 = 1.0f / (1.0f - alpha_bar_i);
+    float t2 = sab * acc;
+    float score = t1 * (-Yi + t2);
+    float t3 = (1.0f - alpha_bar_i) * score;
+    float Yim1 = (1.0f / fsqrt(alpha_i)) * (Yi + t3);
+    out = Yim1 / fsqrt(alpha_bar_im1);
+  }
+  Ybar_im1[e] = out;
+}
+
+}  // namespace mbd

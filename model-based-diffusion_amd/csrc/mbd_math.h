@@ -1,0 +1,247 @@
+// mbd_math.h — arithmetic primitives of the MI355X rollout/score kernels.
+//
+// The numerical contract: every primitive fixes its rounding sequence with
+// explicit fmaf, IEEE-exact +,-,*,/,sqrt (build flags: -ffp-contract=off, no fast-math,
+// -fhip-fp32-correctly-rounded-divide-sqrt) and polynomial kernels for the transcendental functions,
+// so that results are reproducible bit-for-bit across wavefronts, GPUs, shard layouts and the CPU
+// checker used by the tests.  Nothing here depends on ocml's libm.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define MBD_HD __host__ __device__ __forceinline__
+
+namespace mbd {
+
+struct v3 {
+  float x, y, z;
+};
+struct q4 {
+  float w, x, y, z;
+};
+
+MBD_HD float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
+MBD_HD float fsqrt(float x) { return __builtin_sqrtf(x); }
+MBD_HD float fabs_(float x) { return x < 0.0f ? -x : x; }
+MBD_HD float fmin_(float a, float b) { return a < b ? a : b; }
+MBD_HD float fmax_(float a, float b) { return a > b ? a : b; }
+MBD_HD float fclip(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+
+MBD_HD v3 mk3(float x, float y, float z) { return v3{x, y, z}; }
+MBD_HD float dot(v3 a, v3 b) { return ffma(a.x, b.x, ffma(a.y, b.y, a.z * b.z)); }
+MBD_HD v3 cross(v3 a, v3 b) {
+  return v3{ffma(a.y, b.z, -(a.z * b.y)), ffma(a.z, b.x, -(a.x * b.z)), ffma(a.x, b.y, -(a.y * b.x))};
+}
+MBD_HD v3 add(v3 a, v3 b) { return v3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+MBD_HD v3 sub(v3 a, v3 b) { return v3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+MBD_HD v3 scale(v3 a, float s) { return v3{a.x * s, a.y * s, a.z * s}; }
+MBD_HD v3 neg(v3 a) { return v3{-a.x, -a.y, -a.z}; }
+// o + s*a, one fma per component
+MBD_HD v3 axpy(float s, v3 a, v3 o) { return v3{ffma(s, a.x, o.x), ffma(s, a.y, o.y), ffma(s, a.z, o.z)}; }
+MBD_HD v3 sel(bool c, v3 a, v3 b) { return c ? a : b; }
+
+// rotate v by unit quaternion q: t = 2 (u x v); v + w t + u x t
+MBD_HD v3 rot(v3 v, q4 q) {
+  v3 u{q.x, q.y, q.z};
+  v3 t = cross(u, v);
+  t = v3{t.x + t.x, t.y + t.y, t.z + t.z};
+  v3 c = cross(u, t);
+  return v3{ffma(q.w, t.x, v.x) + c.x, ffma(q.w, t.y, v.y) + c.y, ffma(q.w, t.z, v.z) + c.z};
+}
+MBD_HD q4 conj(q4 q) { return q4{q.w, -q.x, -q.y, -q.z}; }
+MBD_HD v3 irot(v3 v, q4 q) { return rot(v, conj(q)); }
+MBD_HD q4 qmul(q4 a, q4 b) {
+  q4 o;
+  o.w = ffma(-a.z, b.z, ffma(-a.y, b.y, ffma(-a.x, b.x, a.w * b.w)));
+  o.x = ffma(-a.z, b.y, ffma(a.y, b.z, ffma(a.x, b.w, a.w * b.x)));
+  o.y = ffma(a.z, b.x, ffma(a.y, b.w, ffma(-a.x, b.z, a.w * b.y)));
+  o.z = ffma(a.z, b.w, ffma(-a.y, b.x, ffma(a.x, b.y, a.w * b.z)));
+  return o;
+}
+MBD_HD q4 qnormalize(q4 q) {
+  float n2 = ffma(q.w, q.w, ffma(q.x, q.x, ffma(q.y, q.y, q.z * q.z)));
+  float inv = 1.0f / fsqrt(n2);
+  return q4{q.w * inv, q.x * inv, q.y * inv, q.z * inv};
+}
+// normalize(q + 0.5 (0,th) (x) q)
+MBD_HD q4 qrotvec(q4 q, v3 th) {
+  float hx = 0.5f * th.x, hy = 0.5f * th.y, hz = 0.5f * th.z;
+  q4 o;
+  o.w = ffma(-hz, q.z, ffma(-hy, q.y, ffma(-hx, q.x, q.w)));
+  o.x = ffma(-hz, q.y, ffma(hy, q.z, ffma(hx, q.w, q.x)));
+  o.y = ffma(hz, q.x, ffma(hy, q.w, ffma(-hx, q.z, q.y)));
+  o.z = ffma(hz, q.w, ffma(-hy, q.x, ffma(hx, q.y, q.z)));
+  return qnormalize(o);
+}
+struct axes3 {
+  v3 X, Y, Z;
+};
+MBD_HD axes3 qaxes(q4 q) {
+  float x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+  float xx = q.x * x2, yy = q.y * y2, zz = q.z * z2;
+  float xy = q.x * y2, xz = q.x * z2, yz = q.y * z2;
+  float wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+  axes3 a;
+  a.X = v3{1.0f - (yy + zz), xy + wz, xz - wy};
+  a.Y = v3{xy - wz, 1.0f - (xx + zz), yz + wx};
+  a.Z = v3{xz + wy, yz - wx, 1.0f - (xx + yy)};
+  return a;
+}
+
+// atan2 with a = min/max in [0,1], atan(a) = a P(a^2) (A&S 4.4.49), octant fix-ups; branch-free
+MBD_HD float atan2_(float y, float x) {
+  float ax = fabs_(x), ay = fabs_(y);
+  float mx = fmax_(ax, ay), mn = fmin_(ax, ay);
+  float a = mx == 0.0f ? 0.0f : mn / mx;
+  float s = a * a;
+  float p = 0.0028662257f;
+  p = ffma(p, s, -0.0161657367f);
+  p = ffma(p, s, 0.0429096138f);
+  p = ffma(p, s, -0.0752896400f);
+  p = ffma(p, s, 0.1065626393f);
+  p = ffma(p, s, -0.1420889944f);
+  p = ffma(p, s, 0.1999355085f);
+  p = ffma(p, s, -0.3333314528f);
+  float r = ffma(p * s, a, a);
+  r = ay > ax ? 1.57079632679489661923f - r : r;
+  r = x < 0.0f ? 3.14159265358979323846f - r : r;
+  return y < 0.0f ? -r : r;
+}
+MBD_HD float asin_(float v) {
+  float c2 = ffma(-v, v, 1.0f);
+  return atan2_(v, fsqrt(c2 < 0.0f ? 0.0f : c2));
+}
+MBD_HD void sincos_(float x, float* s_out, float* c_out) {
+  float k = __builtin_rintf(x * 0.63661977236758134308f);
+  float r = ffma(-k, 1.5703125f, x);
+  r = ffma(-k, 4.837512969970703125e-4f, r);
+  r = ffma(-k, 7.54978995489188216e-8f, r);
+  float z = r * r;
+  float ps = ffma(ffma(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f);
+  float sn = ffma(ps * z, r, r);
+  float pc = ffma(ffma(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f);
+  float cs = ffma(pc * z, z, ffma(-0.5f, z, 1.0f));
+  int q = (int)k & 3;
+  float s = (q & 1) ? cs : sn, c = (q & 1) ? sn : cs;
+  s = (q == 2 || q == 3) ? -s : s;
+  c = (q == 1 || q == 2) ? -c : c;
+  *s_out = s;
+  *c_out = c;
+}
+MBD_HD float exp_(float x) {
+  float k = __builtin_rintf(x * 1.44269504088896341f);
+  float r = ffma(-k, 0.693359375f, x);
+  r = ffma(-k, -2.12194440e-4f, r);
+  float p = 1.9875691500e-4f;
+  p = ffma(p, r, 1.3981999507e-3f);
+  p = ffma(p, r, 8.3334519073e-3f);
+  p = ffma(p, r, 4.1665795894e-2f);
+  p = ffma(p, r, 1.6666665459e-1f);
+  p = ffma(p, r, 5.0000001201e-1f);
+  float e = ffma(p * r, r, r) + 1.0f;
+  float v = __builtin_ldexpf(e, (int)k);
+  v = x < -87.0f ? 0.0f : v;
+  return x > 88.7f ? __builtin_inff() : v;
+}
+MBD_HD float log_(float x) {
+  int e;
+  float m = __builtin_frexpf(x, &e);
+  bool lo = m < 0.707106781186547524f;
+  e = lo ? e - 1 : e;
+  m = lo ? m + m : m;
+  float f = m - 1.0f;
+  float z = f * f;
+  float p = 7.0376836292e-2f;
+  p = ffma(p, f, -1.1514610310e-1f);
+  p = ffma(p, f, 1.1676998740e-1f);
+  p = ffma(p, f, -1.2420140846e-1f);
+  p = ffma(p, f, 1.4249322787e-1f);
+  p = ffma(p, f, -1.6668057665e-1f);
+  p = ffma(p, f, 2.0000714765e-1f);
+  p = ffma(p, f, -2.4999993993e-1f);
+  p = ffma(p, f, 3.3333331174e-1f);
+  float y = (p * f) * z;
+  float fe = (float)e;
+  y = ffma(fe, -2.12194440e-4f, y);
+  y = ffma(-0.5f, z, y);
+  float r = f + y;
+  return ffma(fe, 0.693359375f, r);
+}
+MBD_HD float log1p_(float t) {  // t in (-1, 0]
+  float u = 1.0f + t;
+  if (u == 1.0f) return t;
+  if (u <= 0.0f) return -__builtin_inff();
+  return log_(u) * (t / (u - 1.0f));
+}
+// XLA's f32 ErfInv polynomial (Giles)
+MBD_HD float erfinv_(float x) {
+  float w = -log1p_(-(x * x));
+  bool small = w < 5.0f;
+  float ws = w - 2.5f;
+  float wl = fsqrt(w) - 3.0f;
+  float ww = small ? ws : wl;
+  float p = small ? 2.81022636e-08f : -0.000200214257f;
+  p = ffma(p, ww, small ? 3.43273939e-07f : 0.000100950558f);
+  p = ffma(p, ww, small ? -3.5233877e-06f : 0.00134934322f);
+  p = ffma(p, ww, small ? -4.39150654e-06f : -0.00367342844f);
+  p = ffma(p, ww, small ? 0.00021858087f : 0.00573950773f);
+  p = ffma(p, ww, small ? -0.00125372503f : -0.0076224613f);
+  p = ffma(p, ww, small ? -0.00417768164f : 0.00943887047f);
+  p = ffma(p, ww, small ? 0.246640727f : 1.00167406f);
+  p = ffma(p, ww, small ? 1.50140941f : 2.83297682f);
+  if (fabs_(x) == 1.0f) return x * __builtin_inff();
+  return p * x;
+}
+
+// ---- threefry2x32-20 (JAX PRNG) ---------------------------------------------------------------------
+MBD_HD uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+MBD_HD void threefry2x32(uint32_t k0, uint32_t k1, uint32_t c0, uint32_t c1, uint32_t& o0, uint32_t& o1) {
+  const uint32_t k2 = k0 ^ k1 ^ 0x1BD11BDAu;
+  uint32_t x0 = c0 + k0, x1 = c1 + k1;
+#define MBD_TF_ROUND(r) x0 += x1; x1 = rotl32(x1, r); x1 ^= x0;
+  MBD_TF_ROUND(13) MBD_TF_ROUND(15) MBD_TF_ROUND(26) MBD_TF_ROUND(6)
+  x0 += k1; x1 += k2 + 1u;
+  MBD_TF_ROUND(17) MBD_TF_ROUND(29) MBD_TF_ROUND(16) MBD_TF_ROUND(24)
+  x0 += k2; x1 += k0 + 2u;
+  MBD_TF_ROUND(13) MBD_TF_ROUND(15) MBD_TF_ROUND(26) MBD_TF_ROUND(6)
+  x0 += k0; x1 += k1 + 3u;
+  MBD_TF_ROUND(17) MBD_TF_ROUND(29) MBD_TF_ROUND(16) MBD_TF_ROUND(24)
+  x0 += k1; x1 += k2 + 4u;
+  MBD_TF_ROUND(13) MBD_TF_ROUND(15) MBD_TF_ROUND(26) MBD_TF_ROUND(6)
+  x0 += k2; x1 += k0 + 5u;
+#undef MBD_TF_ROUND
+  o0 = x0;
+  o1 = x1;
+}
+// jax.random.uniform's bit trick
+MBD_HD float bits_to_uniform(uint32_t bits, float minval, float maxval) {
+  uint32_t fb = (bits >> 9) | 0x3F800000u;
+  float f = __builtin_bit_cast(float, fb) - 1.0f;
+  float v = f * (maxval - minval) + minval;
+  return v > minval ? v : minval;
+}
+// jax.random.normal from 32 random bits: sqrt(2) * erfinv(uniform(nextafter(-1,0), 1))
+MBD_HD float bits_to_normal(uint32_t bits) {
+  const float lo = -0.99999994f;  // nextafterf(-1, 0)
+  float u = bits_to_uniform(bits, lo, 1.0f);
+  return 1.41421356237309504880f * erfinv_(u);
+}
+// random bits for flat element j of `size` elements (legacy = jax_threefry_partitionable False)
+MBD_HD uint32_t random_bits32(uint32_t k0, uint32_t k1, int impl, uint64_t j, uint64_t size) {
+  uint32_t o0, o1;
+  if (impl == 1) {
+    threefry2x32(k0, k1, (uint32_t)(j >> 32), (uint32_t)j, o0, o1);
+    return o0 ^ o1;
+  }
+  uint64_t half = (size + 1) / 2;
+  if (j < half) {
+    uint64_t c1 = j + half;
+    threefry2x32(k0, k1, (uint32_t)j, c1 < size ? (uint32_t)c1 : 0u, o0, o1);
+    return o0;
+  }
+  threefry2x32(k0, k1, (uint32_t)(j - half), (uint32_t)j, o0, o1);
+  return o1;
+}
+
+}  // namespace mbd

@@ -1,0 +1,21 @@
+"""Per-environment constants taken from the reference's env wrappers."""
+
+SPECS = {
+    # mbd/envs/humanoidrun.py:14-17,21-27
+    "humanoidrun": dict(xml="humanoidrun.xml", from_reference=True, n_frames=7, reset_noise=0.01),
+    # mbd/envs/humanoidtrack.py:15-46 (reset is deterministic, :48-61); the five *_ref marker links are
+    # world-parented, collision-free and dynamically decoupled from the humanoid (humanoidtrack.xml:152-180),
+    # and only overwritten for visualisation (:67-74): the compiled model drops them.
+    "humanoidtrack": dict(xml="humanoidtrack.xml", from_reference=True, n_frames=5, reset_noise=0.0,
+                          drop_suffix="_ref",
+                          track=("torso", "left_thigh", "right_thigh", "left_shin", "right_shin")),
+    # mbd/envs/hopper.py:12-18 (_reset_noise_scale 5e-3, n_frames 20); XML re-authored (see assets/hopper.xml)
+    "hopper": dict(xml="hopper.xml", from_reference=False, n_frames=20, reset_noise=5e-3),
+    # brax.envs.half_cheetah (absent): n_frames 16 @ 0.003125 s, reset noise 0.1, forward_reward_weight 1,
+    # ctrl_cost_weight 0.1 — recollection, unpinned
+    "halfcheetah": dict(xml="halfcheetah.xml", from_reference=False, n_frames=16, reset_noise=0.1,
+                        reward_params=(1.0, 0.1)),
+}
+
+# names mbd.envs.get_env knows (mbd/envs/__init__.py:13-33) that are outside the hot-path scope
+OUT_OF_SCOPE = ("pushT", "humanoidstandup", "walker2d", "cartpole", "ant")

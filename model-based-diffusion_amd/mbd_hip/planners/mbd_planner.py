@@ -1,0 +1,236 @@
+"""Drop-in for mbd/planners/mbd_planner.py: same ``Args`` fields and defaults (:18-35), same
+recommended-parameter overrides (:45-68), same RNG chain (:40,79,150,103), same return value (:182).
+
+The reverse loop (:138-148) runs through libmbd_hip.so.  With ``torch.distributed`` initialised the N
+candidates are sharded over ranks (one process per GPU): per diffusion step each rank rolls out its
+shard, ONE all-gather (RCCL over xGMI) exchanges the N mean rewards, and every rank finishes the
+step redundantly from identical inputs — results are bit-identical for every world size.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+from dataclasses import dataclass
+
+import numpy as np
+
+from .. import _capi
+from ..envs import get_env
+from ..envs.base import prng_impl
+
+
+@dataclass
+class Args:
+    # exp
+    seed: int = 0
+    disable_recommended_params: bool = False
+    not_render: bool = False
+    # env
+    env_name: str = "ant"  # in scope here: "car2d", "hopper", "halfcheetah", "humanoidrun", "humanoidtrack"
+    # diffusion
+    Nsample: int = 2048  # number of samples
+    Hsample: int = 50  # horizon
+    Ndiffuse: int = 100  # number of diffusion steps
+    temp_sample: float = 0.1  # temperature for sampling
+    beta0: float = 1e-4  # initial beta
+    betaT: float = 1e-2  # final beta
+    enable_demo: bool = False
+
+
+# mbd_planner.py:45-63
+TEMP_RECOMMEND = {"ant": 0.1, "halfcheetah": 0.4, "hopper": 0.1, "humanoidstandup": 0.1, "humanoidrun": 0.1,
+                  "walker2d": 0.1, "pushT": 0.2}
+NDIFFUSE_RECOMMEND = {"pushT": 200, "humanoidrun": 300}
+NSAMPLE_RECOMMEND = {"humanoidrun": 8192}
+HSAMPLE_RECOMMEND = {"pushT": 40}
+
+
+def apply_recommended(args: Args) -> None:
+    if not args.disable_recommended_params:  # mbd_planner.py:64-69
+        args.temp_sample = TEMP_RECOMMEND.get(args.env_name, args.temp_sample)
+        args.Ndiffuse = NDIFFUSE_RECOMMEND.get(args.env_name, args.Ndiffuse)
+        args.Nsample = NSAMPLE_RECOMMEND.get(args.env_name, args.Nsample)
+        args.Hsample = HSAMPLE_RECOMMEND.get(args.env_name, args.Hsample)
+        print(f"override temp_sample to {args.temp_sample}")
+
+
+class Plan:
+    """Thin owner of an ``mbd_plan`` handle."""
+
+    def __init__(self, env, args: Args, shard_begin: int = 0, shard_count: int = None, literal_score: bool = True):
+        self.lib = _capi.load()
+        self.env = env
+        cfg = _capi.PlanConfig()
+        cfg.Nsample, cfg.Hsample, cfg.Ndiffuse = args.Nsample, args.Hsample, args.Ndiffuse
+        cfg.temp_sample, cfg.beta0, cfg.betaT = args.temp_sample, args.beta0, args.betaT
+        cfg.enable_demo = int(args.enable_demo)
+        cfg.prng_impl = prng_impl()
+        cfg.shard_begin = shard_begin
+        cfg.shard_count = args.Nsample if shard_count is None else shard_count
+        cfg.literal_score = int(literal_score)
+        self.cfg = cfg
+        h = C.c_void_p()
+        _capi.check(self.lib.mbd_plan_create(env.handle, C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.Nd, self.H, self.Nu = args.Ndiffuse, args.Hsample, env.action_size
+
+    def schedule(self):
+        a, ab, s = (np.zeros(self.Nd, np.float32) for _ in range(3))
+        _capi.check(self.lib.mbd_plan_schedule(self.h, _capi.np_ptr(a), _capi.np_ptr(ab), _capi.np_ptr(s)))
+        return a, ab, s
+
+    def set_state0(self, state):
+        st = np.ascontiguousarray(state.pipeline_state, np.float32).reshape(-1)
+        _capi.check(self.lib.mbd_plan_set_state0(self.h, _capi.np_ptr(st)))
+
+    def enable_timing(self, on=True):
+        _capi.check(self.lib.mbd_plan_enable_timing(self.h, int(on)))
+
+    def kernel_time(self, reset=True):
+        ms, n = C.c_float(), C.c_int()
+        _capi.check(self.lib.mbd_plan_kernel_time(self.h, C.byref(ms), C.byref(n), int(reset)))
+        return ms.value, n.value
+
+    def run(self, key):
+        """Whole reverse loop on one GPU. Returns (mu_0ts [Nd-1,H,Nu], rew_means [Nd-1], rew_final, secs)."""
+        mu = np.zeros((self.Nd - 1, self.H, self.Nu), np.float32)
+        rm = np.zeros(self.Nd - 1, np.float32)
+        rf, secs = C.c_float(), C.c_double()
+        _capi.check(self.lib.mbd_plan_run(self.h, _capi.key_array(key), _capi.np_ptr(mu), _capi.np_ptr(rm),
+                                          C.byref(rf), C.byref(secs)))
+        return mu, rm, rf.value, secs.value
+
+    def eval(self, Y) -> float:
+        Y = np.ascontiguousarray(Y, np.float32)
+        rf = C.c_float()
+        _capi.check(self.lib.mbd_plan_eval(self.h, _capi.np_ptr(Y), C.byref(rf)))
+        return rf.value
+
+    def peek(self, want_weights=True):
+        N, sh = self.cfg.Nsample, self.cfg.shard_count
+        Y0s = np.zeros((N, self.H, self.Nu), np.float32)
+        rewss = np.zeros((sh, self.H), np.float32)
+        w = np.zeros(N, np.float32)
+        _capi.check(self.lib.mbd_plan_peek(self.h, _capi.np_ptr(Y0s), _capi.np_ptr(rewss), _capi.np_ptr(w)))
+        return Y0s, rewss, w
+
+    def close(self):
+        if self.h is not None:
+            self.lib.mbd_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bool = False):
+    """reverse() (mbd_planner.py:138-148) with the candidates sharded over the ranks of ``group``.
+    One all-gather of the per-candidate mean rewards per diffusion step (plus the demo log-densities
+    when enabled, packed in the same buffer). Returns (mu_0ts, rew_means) as CUDA tensors."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    N, sh = plan.cfg.Nsample, plan.cfg.shard_count
+    demo = bool(plan.cfg.enable_demo)
+    rows = 2 if demo else 1
+    HNu = plan.H * plan.Nu
+    dev = torch.device("cuda", device)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    mu = torch.zeros((plan.Nd - 1, HNu), dtype=torch.float32, device=dev)
+    rew_means = torch.zeros(plan.Nd - 1, dtype=torch.float32, device=dev)
+    Ybar = torch.zeros(HNu, dtype=torch.float32, device=dev)  # YN = zeros (mbd_planner.py:95)
+    local = torch.zeros((rows, sh), dtype=torch.float32, device=dev)
+    gathered = torch.zeros((world, rows, sh), dtype=torch.float32, device=dev)
+    allv = torch.zeros((rows, N), dtype=torch.float32, device=dev)
+    rng = np.asarray(key, np.uint32)
+    impl = plan.cfg.prng_impl
+    lib = plan.lib
+    for i in range(plan.Nd - 1, 0, -1):
+        keys = _capi.prng_split(rng, 2, impl)  # rng, Y0s_rng = split(rng)  (mbd_planner.py:103)
+        rng, ks = keys[0], _capi.key_array(keys[1])
+        _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Ybar.data_ptr(), local[0].data_ptr(),
+                                                local[1].data_ptr() if demo else None, stream))
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, local, group=group)
+            allv.copy_(gathered.permute(1, 0, 2).reshape(rows, N))
+        else:
+            allv.copy_(local)
+        out = mu[plan.Nd - 1 - i]
+        _capi.check(lib.mbd_plan_score_update(plan.h, i, ks, Ybar.data_ptr(), allv[0].data_ptr(),
+                                              allv[1].data_ptr() if demo else None, out.data_ptr(),
+                                              rew_means[plan.Nd - 1 - i:].data_ptr(), stream))
+        Ybar = out
+        if sync_every_step:  # the reference formats the reward every step (mbd_planner.py:147)
+            float(rew_means[plan.Nd - 1 - i])
+    return mu.view(plan.Nd - 1, plan.H, plan.Nu), rew_means
+
+
+def run_diffusion(args: Args, device: int = None, return_details: bool = False):
+    """mbd_planner.py:38-182. Returns rew_final (float); ``return_details`` adds a dict with mu_0ts,
+    per-step mean rewards and the reverse-loop wall time."""
+    import torch
+    import torch.distributed as dist
+
+    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0")) if distributed else 0
+    rng = _capi.prng_key(args.seed)  # :40
+    apply_recommended(args)
+    env = get_env(args.env_name, device=device)  # :70
+    impl = prng_impl()
+    rng, rng_reset = _capi.prng_split(rng, 2, impl)  # :79  NOTE: rng_reset should never be changed.
+    state_init = env.reset(rng_reset)  # :80
+    rng_exp, rng = _capi.prng_split(rng, 2, impl)  # :150
+
+    if distributed:
+        world, rank = dist.get_world_size(), dist.get_rank()
+        if args.Nsample % world:
+            raise ValueError(f"Nsample={args.Nsample} must be divisible by the world size {world}")
+        sh = args.Nsample // world
+        plan = Plan(env, args, shard_begin=rank * sh, shard_count=sh)
+    else:
+        plan = Plan(env, args)
+    plan.set_state0(state_init)
+    _, _, sigmas = plan.schedule()
+    print(f"init sigma = {sigmas[-1]:.2e}")  # :93
+
+    if distributed:
+        torch.cuda.set_device(device)
+        torch.cuda.synchronize(device)
+        t0 = time.time()
+        mu_t, rm_t = reverse_distributed(plan, rng_exp, device)
+        torch.cuda.synchronize(device)
+        secs = time.time() - t0
+        mu, rew_means = mu_t.cpu().numpy(), rm_t.cpu().numpy()
+        rew_final = plan.eval(mu[-1])  # :179-180
+    else:
+        mu, rew_means, rew_final, secs = plan.run(rng_exp)
+
+    if not args.not_render and (not distributed or dist.get_rank() == 0):  # :152-156 (mu_0ts.npy only)
+        path = os.path.join(os.getcwd(), "results", args.env_name)
+        os.makedirs(path, exist_ok=True)
+        np.save(os.path.join(path, "mu_0ts.npy"), mu)
+    plan.close()
+    if return_details:
+        return rew_final, dict(mu_0ts=mu, rew_means=rew_means, loop_seconds=secs, state_init=state_init,
+                               steps_per_sec=(args.Ndiffuse - 1) / secs)
+    return rew_final
+
+
+if __name__ == "__main__":
+    import argparse
+
+    p = argparse.ArgumentParser()
+    for f in Args.__dataclass_fields__.values():
+        if f.type in ("bool", bool):
+            p.add_argument(f"--{f.name}", action="store_true")
+        else:
+            p.add_argument(f"--{f.name}", type=type(f.default), default=f.default)
+    ns = p.parse_args()
+    rew_final = run_diffusion(Args(**vars(ns)))
+    print(f"final reward = {rew_final:.2e}")  # :187

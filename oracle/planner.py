@@ -1,0 +1,97 @@
+"""CPU restatement of run_diffusion / reverse_once (mbd/planners/mbd_planner.py:38-182) on top of the C
+oracle — TEST INFRASTRUCTURE ONLY (tests/, smoke(), bench.py's cpu_baseline leg)."""
+from __future__ import annotations
+
+import numpy as np
+
+from .oracle import Oracle
+
+
+class OracleEnv:
+    """Minimal env adaptor: kind 'car2d' or a compiled model struct (ctypes, laid out as mbd_model_t)."""
+
+    def __init__(self, orc: Oracle, name: str, model_struct=None, xref=None, rew_xref: float = 0.0,
+                 init_q=None):
+        self.orc, self.name, self.ms, self.xref, self.rew_xref = orc, name, model_struct, xref, rew_xref
+        self.init_q = init_q
+        self.Nu = 2 if name == "car2d" else model_struct.n_act
+
+    def reset(self, key, impl):
+        """humanoidrun.py:19-32 / hopper.py:20-34 / humanoidtrack.py:48-61 / car2d.py:73-75"""
+        if self.name == "car2d":
+            return self.orc.car2d_reset()
+        m = self.ms
+        q = np.array(self.init_q, np.float32)
+        qd = np.zeros(m.n_qd, np.float32)
+        s = np.float32(m.reset_noise)
+        if s > 0:
+            keys = self.orc.split(key, 3, impl)
+            q = (q + self.orc.uniform(keys[1], m.n_q, -s, s, impl)).astype(np.float32)
+            if self.name == "halfcheetah":
+                qd = (s * self.orc.normal(keys[2], (m.n_qd,), impl)).astype(np.float32)
+            else:
+                qd = self.orc.uniform(keys[2], m.n_qd, -s, s, impl)
+        return self.orc.forward(m, q, qd)
+
+    def rollout(self, state0, us, want_xpos=False):
+        if self.name == "car2d":
+            return self.orc.car2d_rollout(state0, us, want_qs=want_xpos)
+        return self.orc.rollout(self.ms, state0, us, want_xpos=want_xpos)
+
+    def logpd(self, xpos):
+        if self.name == "car2d":
+            return np.array([self.orc.car2d_xref_logpd(x, self.xref) for x in xpos], np.float32)
+        return np.array([self.orc.track_xref_logpd(x, self.xref) for x in xpos], np.float32)
+
+
+def mean_h(orc: Oracle, rewss):
+    out = np.zeros(rewss.shape[0], np.float32)
+    orc.lib.orc_mean_h.argtypes = None
+    import ctypes as C
+    orc.lib.orc_mean_h(rewss.ctypes.data_as(C.c_void_p), C.c_int(rewss.shape[0]), C.c_int(rewss.shape[1]),
+                       out.ctypes.data_as(C.c_void_p))
+    return out
+
+
+def reverse_once(orc: Oracle, env: OracleEnv, state0, i, rng, Ybar_i, sched, N, H, temp, impl,
+                 enable_demo=False, literal=True):
+    """One step of mbd_planner.py:97-135. Returns (rng', Ybar_im1, rew_mean, details)."""
+    alphas, alphas_bar, sigmas = sched
+    keys = orc.split(rng, 2, impl)  # rng, Y0s_rng = split(rng)  (:103)
+    rng, ks = keys[0], keys[1]
+    Y0s = orc.sample(ks, impl, N, H, env.Nu, 0, N, float(sigmas[i]), Ybar_i)  # :104-106
+    lp = None
+    if enable_demo:
+        rewss, xpos = env.rollout(state0, Y0s, want_xpos=True)  # :109
+        lp = env.logpd(xpos)  # :118
+    else:
+        rewss = env.rollout(state0, Y0s)
+    rews = mean_h(orc, np.ascontiguousarray(rewss))  # :110
+    Ybar_im1, w, rew_mean = orc.score_update(rews, Y0s, Ybar_i, float(alphas[i]), float(alphas_bar[i]),
+                                             float(alphas_bar[i - 1]), temp, lp_demo=lp,
+                                             rew_xref=env.rew_xref, literal=literal)  # :111-135
+    return rng, Ybar_im1, rew_mean, dict(Y0s=Y0s, rewss=rewss, rews=rews, weights=w, lp=lp)
+
+
+def run_diffusion(orc: Oracle, env: OracleEnv, seed, N, H, Nd, temp, beta0=1e-4, betaT=1e-2, impl=1,
+                  enable_demo=False, literal=True, max_steps=None):
+    """mbd_planner.py:38-182 (RNG chain :40,79,150). Returns dict(mu_0ts, rew_means, rew_final, state_init)."""
+    rng = orc.prng_key(seed)
+    rng, rng_reset = orc.split(rng, 2, impl)
+    state0 = env.reset(rng_reset, impl)
+    sched = orc.schedule(beta0, betaT, Nd)
+    rng_exp, rng = orc.split(rng, 2, impl)
+    Ybar = np.zeros((H, env.Nu), np.float32)
+    mus, rms = [], []
+    r = rng_exp
+    steps = 0
+    for i in range(Nd - 1, 0, -1):
+        r, Ybar, rm, _ = reverse_once(orc, env, state0, i, r, Ybar, sched, N, H, temp, impl, enable_demo, literal)
+        mus.append(Ybar)
+        rms.append(rm)
+        steps += 1
+        if max_steps is not None and steps >= max_steps:
+            break
+    rew_final = mean_h(orc, np.ascontiguousarray(env.rollout(state0, Ybar[None])))[0]  # :179-180
+    return dict(mu_0ts=np.stack(mus), rew_means=np.array(rms, np.float32), rew_final=rew_final,
+                state_init=state0)

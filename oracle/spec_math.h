@@ -158,7 +158,7 @@ static inline void sp_sincos(real x, real* s_out, real* c_out) {
 /* everything below is float32-only (sampling / softmax never run in the f64 build) */
 static inline float sp_exp_f32(float x) {
   /* e^x = 2^k * e^r, k = rint(x*log2e), r = x - k*ln2 (two-part), degree-6 Taylor-minimax (cephes) */
-  if (x < -104.0f) return 0.0f;
+  if (x < -87.0f) return 0.0f; /* keeps the result a normal number */
   if (x > 88.7f) return INFINITY;
   float k = __builtin_rintf(x * 1.44269504088896341f);
   float r = __builtin_fmaf(-k, 0.693359375f, x);

@@ -1,0 +1,42 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "model-based-diffusion_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` through gpurun)")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    from oracle import oracle
+    oracle.build()
+    return oracle.Oracle("f32")
+
+
+@pytest.fixture(scope="session")
+def orc64():
+    from oracle import oracle
+    oracle.build()
+    return oracle.Oracle("f64")
+
+
+@pytest.fixture(scope="session")
+def lib():
+    import __graft_entry__
+    __graft_entry__.build()
+    from mbd_hip import _capi
+    return _capi.load()
+
+
+def load_model(name):
+    from mbd_hip.model import Model
+    path = os.path.join(ROOT, "model-based-diffusion_amd", "assets", "compiled", f"{name}.json")
+    with open(path) as f:
+        return Model.from_json(f.read())
