@@ -57,6 +57,13 @@ def load() -> C.CDLL:
     if not os.path.exists(path):
         raise MbdError(MBD_ERR_STATE, f"{path} is missing: run `python __graft_entry__.py` (build()) first; "
                                       "mbd_hip has no CPU fallback")
+    # torch (device memory / streams / torch.distributed plumbing) bundles its own HIP runtime with the
+    # same SONAME as the system one: it has to be the first one mapped, or two runtimes fight over the
+    # device ("No HIP GPUs are available")
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(path)
     lib.mbd_last_error.restype = C.c_char_p
     lib.mbd_device_count.argtypes = [C.POINTER(_i)]
