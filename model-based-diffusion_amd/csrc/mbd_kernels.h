@@ -66,7 +66,7 @@ struct JointFrames {
   v3 ap, ac;
   q4 aprot;
   v3 Xp, Xc, Yc, Zc, ax1;
-  float ang[3];
+  float ang0, ang1, ang2;
 };
 
 struct JointConst {
@@ -82,9 +82,9 @@ __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp,
   q4 acrot = qmul(Cr, jc.ac_rot);
   axes3 A = qaxes(f.aprot), C = qaxes(acrot);
   f.Xp = A.X; f.Xc = C.X; f.Yc = C.Y; f.Zc = C.Z;
-  f.ang[0] = atan2_(-dot(C.Z, A.Y), dot(C.Z, A.Z));
-  f.ang[1] = asin_(fclip(dot(C.Z, A.X), -1.0f, 1.0f));
-  f.ang[2] = atan2_(-dot(C.Y, A.X), dot(C.X, A.X));
+  f.ang0 = atan2_(-dot(C.Z, A.Y), dot(C.Z, A.Z));
+  f.ang1 = asin_(fclip(dot(C.Z, A.X), -1.0f, 1.0f));
+  f.ang2 = atan2_(-dot(C.Y, A.X), dot(C.X, A.X));
   v3 n = cross(C.Z, A.X);
   float inv = 1.0f / (fsqrt(dot(n, n)) + 1e-10f);
   f.ax1 = scale(n, inv);
@@ -264,14 +264,15 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         v3 vc = add(v, cross(w, rc)), vp = add(Pv, cross(Pw, rp));
         v3 rel_v = sub(vc, vp), rel_w = sub(w, Pw);
         v3 T = mk3(0, 0, 0), F = mk3(0, 0, 0);
-        const v3 axk[3] = {f.Xp, f.ax1, f.Zc};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          float qdk = dot(rel_w, axk[k]);
-          float fk = ffma(-stiff[k], f.ang[k], ffma(-damp[k], qdk, tau[k]));
+        auto torque = [&](int k, v3 ax, float ang) {
+          float qdk = dot(rel_w, ax);
+          float fk = ffma(-stiff[k], ang, ffma(-damp[k], qdk, tau[k]));
           fk = k < nr ? fk : 0.0f;
-          T = axpy(fk, axk[k], T);
-        }
+          T = axpy(fk, ax, T);
+        };
+        torque(0, f.Xp, f.ang0);
+        torque(1, f.ax1, f.ang1);
+        torque(2, f.Zc, f.ang2);
         if constexpr (SLIDES) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
@@ -296,8 +297,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         const bool has = child_lane[c] >= 0;
         const int src = has ? child_lane[c] : lane;
         v3 cv = shfl3(fp_v, src), cw = shfl3(fp_w, src);
-        av = has ? add(av, cv) : av;
-        aw = has ? add(aw, cw) : aw;
+        av = sel3(has, add(av, cv), av);
+        aw = sel3(has, add(aw, cw), aw);
       }
       v = mk3(ffma(av.x + grav.x, dt, vel_fac * v.x), ffma(av.y + grav.y, dt, vel_fac * v.y),
               ffma(av.z + grav.z, dt, vel_fac * v.z));
@@ -336,19 +337,19 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         dp_p = scale(Pimp, -ip.inv_mass);
         dp_th = scale(iinv<ISO>(ip, Pr, cross(rp, Pimp)), -1.0f);
         // angular alignment by joint type (1 hinge: Xc || Xp; 2 hinges: Yc _|_ Xp; 3: free)
-        v3 A = nr == 1 ? f.Xc : f.Xp;
-        v3 Bv = nr == 1 ? f.Xp : f.Yc;
+        v3 A = sel3(nr == 1, f.Xc, f.Xp);
+        v3 Bv = sel3(nr == 1, f.Xp, f.Yc);
         float sc = nr == 1 ? 1.0f : (nr == 2 ? dot(f.Xp, f.Yc) : 0.0f);
         v3 e = scale(cross(A, Bv), sc);
         ang_correct<ISO>(e, ip, Pr, ic, r, js_ang, dp_th, dc_th);
-        const v3 axk[3] = {f.Xp, f.ax1, f.Zc};
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          float a = f.ang[k];
+        auto limit = [&](int k, v3 ax, float a) {
           float viol = a < lim_lo[k] ? a - lim_lo[k] : (a > lim_hi[k] ? a - lim_hi[k] : 0.0f);
           viol = k < nr ? viol : 0.0f;
-          ang_correct<ISO>(scale(axk[k], -viol), ip, Pr, ic, r, js_ang, dp_th, dc_th);
-        }
+          ang_correct<ISO>(scale(ax, -viol), ip, Pr, ic, r, js_ang, dp_th, dc_th);
+        };
+        limit(0, f.Xp, f.ang0);
+        limit(1, f.ax1, f.ang1);
+        limit(2, f.Zc, f.ang2);
         if (!is_joint) { dc_p = dc_th = dp_p = dp_th = mk3(0, 0, 0); }
       }
       {
@@ -358,8 +359,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           const bool has = child_lane[c] >= 0;
           const int src = has ? child_lane[c] : lane;
           v3 cp = shfl3(dp_p, src), cth = shfl3(dp_th, src);
-          dp = has ? add(dp, cp) : dp;
-          dth = has ? add(dth, cth) : dth;
+          dp = sel3(has, add(dp, cp), dp);
+          dth = sel3(has, add(dth, cth), dth);
         }
         p = add(p, dp);
         r = qrotvec(r, dth);
@@ -393,17 +394,17 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           v3 icnt = iinv<ISO>(ic, r, cnt);
           float wt = ic.inv_mass + dot(cnt, icnt);
           float dlamt = -(ct / wt);
-          Pimp = fabs_(dlamt) < mu * dlam ? axpy(dlamt, nt, Pimp) : Pimp;
+          Pimp = sel3(fabs_(dlamt) < mu * dlam, axpy(dlamt, nt, Pimp), Pimp);
           v3 ncd_p = axpy(ic.inv_mass, Pimp, cd_p);
           v3 ncd_th = add(cd_th, iinv<ISO>(ic, r, cross(rc, Pimp)));
-          cd_p = active ? ncd_p : cd_p;
-          cd_th = active ? ncd_th : cd_th;
+          cd_p = sel3(active, ncd_p, cd_p);
+          cd_th = sel3(active, ncd_th, cd_th);
           con_pos[j] = pos; con_dlam[j] = dlam; con_act[j] = active;
         }
         v3 np = add(p, cd_p);
         q4 nr_ = qrotvec(r, cd_th);
-        p = any_col ? np : p;
-        r = any_col ? nr_ : r;
+        p = sel3(any_col, np, p);
+        r = sel4(any_col, nr_, r);
       }
       // ---- (5) integrator.project_xd ------------------------------------------------------------------
       const v3 v_old = v, w_old = w;
@@ -435,8 +436,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         v3 Pimp = axpy(jt, dir, scale(nrm, jn));
         v3 nv = axpy(ic.inv_mass, Pimp, v);
         v3 nw = add(w, iinv<ISO>(ic, r, cross(rc, Pimp)));
-        v = con_act[j] ? nv : v;
-        w = con_act[j] ? nw : w;
+        v = sel3(con_act[j], nv, v);
+        w = sel3(con_act[j], nw, w);
       }
     }  // substeps
 

@@ -39,7 +39,7 @@ MBD_HD v3 scale(v3 a, float s) { return v3{a.x * s, a.y * s, a.z * s}; }
 MBD_HD v3 neg(v3 a) { return v3{-a.x, -a.y, -a.z}; }
 // o + s*a, one fma per component
 MBD_HD v3 axpy(float s, v3 a, v3 o) { return v3{ffma(s, a.x, o.x), ffma(s, a.y, o.y), ffma(s, a.z, o.z)}; }
-MBD_HD v3 sel(bool c, v3 a, v3 b) { return c ? a : b; }
+MBD_HD v3 sel3(bool c, v3 a, v3 b) { return v3{c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
 
 // rotate v by unit quaternion q: t = 2 (u x v); v + w t + u x t
 MBD_HD v3 rot(v3 v, q4 q) {
@@ -49,6 +49,7 @@ MBD_HD v3 rot(v3 v, q4 q) {
   v3 c = cross(u, t);
   return v3{ffma(q.w, t.x, v.x) + c.x, ffma(q.w, t.y, v.y) + c.y, ffma(q.w, t.z, v.z) + c.z};
 }
+MBD_HD q4 sel4(bool c, q4 a, q4 b) { return q4{c ? a.w : b.w, c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
 MBD_HD q4 conj(q4 q) { return q4{q.w, -q.x, -q.y, -q.z}; }
 MBD_HD v3 irot(v3 v, q4 q) { return rot(v, conj(q)); }
 MBD_HD q4 qmul(q4 a, q4 b) {
