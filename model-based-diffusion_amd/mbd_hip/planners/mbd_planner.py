@@ -127,6 +127,28 @@ class Plan:
             pass
 
 
+def shard_bounds(N: int, world: int, rank: int):
+    """Candidates [begin, begin+count) owned by `rank`: contiguous, equal shards (N % world == 0)."""
+    if N % world:
+        raise ValueError(f"Nsample={N} must be divisible by the world size {world}")
+    sh = N // world
+    return rank * sh, sh
+
+
+def exchange_rewards(local, world: int, group=None):
+    """The ONE exchange step of a diffusion step: every rank contributes the per-candidate values of its
+    shard (``local`` [rows, shard]) and receives all N of them, rank-major = candidate order, as
+    [rows, N].  One all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests)."""
+    import torch
+    import torch.distributed as dist
+    if world == 1:
+        return local
+    rows, sh = local.shape
+    gathered = torch.empty((world * rows, sh), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)  # concatenation along dim 0
+    return gathered.view(world, rows, sh).permute(1, 0, 2).reshape(rows, world * sh).contiguous()
+
+
 def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bool = False):
     """reverse() (mbd_planner.py:138-148) with the candidates sharded over the ranks of ``group``.
     One all-gather of the per-candidate mean rewards per diffusion step (plus the demo log-densities
@@ -145,8 +167,6 @@ def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bo
     rew_means = torch.zeros(plan.Nd - 1, dtype=torch.float32, device=dev)
     Ybar = torch.zeros(HNu, dtype=torch.float32, device=dev)  # YN = zeros (mbd_planner.py:95)
     local = torch.zeros((rows, sh), dtype=torch.float32, device=dev)
-    gathered = torch.zeros((world, rows, sh), dtype=torch.float32, device=dev)
-    allv = torch.zeros((rows, N), dtype=torch.float32, device=dev)
     rng = np.asarray(key, np.uint32)
     impl = plan.cfg.prng_impl
     lib = plan.lib
@@ -155,11 +175,7 @@ def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bo
         rng, ks = keys[0], _capi.key_array(keys[1])
         _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Ybar.data_ptr(), local[0].data_ptr(),
                                                 local[1].data_ptr() if demo else None, stream))
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, local, group=group)
-            allv.copy_(gathered.permute(1, 0, 2).reshape(rows, N))
-        else:
-            allv.copy_(local)
+        allv = exchange_rewards(local, world, group)
         out = mu[plan.Nd - 1 - i]
         _capi.check(lib.mbd_plan_score_update(plan.h, i, ks, Ybar.data_ptr(), allv[0].data_ptr(),
                                               allv[1].data_ptr() if demo else None, out.data_ptr(),
@@ -188,11 +204,8 @@ def run_diffusion(args: Args, device: int = None, return_details: bool = False):
     rng_exp, rng = _capi.prng_split(rng, 2, impl)  # :150
 
     if distributed:
-        world, rank = dist.get_world_size(), dist.get_rank()
-        if args.Nsample % world:
-            raise ValueError(f"Nsample={args.Nsample} must be divisible by the world size {world}")
-        sh = args.Nsample // world
-        plan = Plan(env, args, shard_begin=rank * sh, shard_count=sh)
+        begin, sh = shard_bounds(args.Nsample, dist.get_world_size(), dist.get_rank())
+        plan = Plan(env, args, shard_begin=begin, shard_count=sh)
     else:
         plan = Plan(env, args)
     plan.set_state0(state_init)

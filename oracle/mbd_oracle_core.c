@@ -393,3 +393,13 @@ ORC_API float orc_track_xref_logpd(const float* xpos, const float* xref, int H, 
     }
   return 0.0f - acc / (float)(H * K);
 }
+
+/* ---- test hooks for the numerical-contract primitives (tests/test_spec_math.py) ------------------ */
+ORC_API float orc_sp_atan2(float y, float x) { return sp_atan2(y, x); }
+ORC_API float orc_sp_asin(float v) { return sp_asin(v); }
+ORC_API void orc_sp_sincos(float x, float* s, float* c) { sp_sincos(x, s, c); }
+ORC_API float orc_sp_exp(float x) { return sp_exp_f32(x); }
+ORC_API float orc_sp_log1p(float t) { return sp_log1p_f32(t); }
+ORC_API void orc_sp_rot(const float v[3], const float q[4], float o[3]) { sp_rot(v, q, o); }
+ORC_API void orc_sp_qmul(const float a[4], const float b[4], float o[4]) { sp_qmul(a, b, o); }
+ORC_API float orc_sp_sum(const float* x, int n) { return sum_f32(x, n); }

@@ -72,6 +72,18 @@ class Oracle:
         lib.orc_forward.argtypes = [C.c_void_p, _f32p, _f32p, _f32p]
         lib.orc_link_positions.argtypes = [C.c_void_p, _f32p, _f32p]
         lib.orc_joint_angles.argtypes = [C.c_void_p, _f32p, _f32p]
+        for fn in ("orc_sp_atan2", "orc_sp_asin", "orc_sp_exp", "orc_sp_log1p"):
+            getattr(lib, fn).restype = C.c_float
+        lib.orc_sp_atan2.argtypes = [C.c_float, C.c_float]
+        lib.orc_sp_asin.argtypes = [C.c_float]
+        lib.orc_sp_exp.argtypes = [C.c_float]
+        lib.orc_sp_log1p.argtypes = [C.c_float]
+        lib.orc_sp_sincos.argtypes = [C.c_float, C.POINTER(C.c_float), C.POINTER(C.c_float)]
+        lib.orc_sp_rot.argtypes = [_f32p, _f32p, _f32p]
+        lib.orc_sp_qmul.argtypes = [_f32p, _f32p, _f32p]
+        lib.orc_sp_sum.argtypes = [_f32p, C.c_int]
+        lib.orc_sp_sum.restype = C.c_float
+        lib.orc_mean_h.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.orc_real_bytes.restype = C.c_int
         lib.orc_model_bytes.restype = C.c_int
 

@@ -46,10 +46,8 @@ class OracleEnv:
 
 def mean_h(orc: Oracle, rewss):
     out = np.zeros(rewss.shape[0], np.float32)
-    orc.lib.orc_mean_h.argtypes = None
-    import ctypes as C
-    orc.lib.orc_mean_h(rewss.ctypes.data_as(C.c_void_p), C.c_int(rewss.shape[0]), C.c_int(rewss.shape[1]),
-                       out.ctypes.data_as(C.c_void_p))
+    rewss = np.ascontiguousarray(rewss, np.float32)
+    orc.lib.orc_mean_h(rewss.ctypes.data, rewss.shape[0], rewss.shape[1], out.ctypes.data)
     return out
 
 

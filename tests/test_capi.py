@@ -1,0 +1,85 @@
+"""The C-ABI boundary without a GPU: the library loads, exports every symbol include/mbd_hip.h declares,
+agrees with the oracle on the struct layout and the host-side PRNG, and fails LOUDLY without a device."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_model
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mbd_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mbd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = _declared()
+    assert len(names) >= 24
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/mbd_hip.h but not exported"
+    from mbd_hip import _capi
+    assert sorted(_capi.EXPORTS) == names
+
+
+def test_struct_layout_agrees_between_ctypes_header_and_oracle(lib, orc):
+    from mbd_hip.model import MbdModel
+    assert C.sizeof(MbdModel) == orc.lib.orc_model_bytes()
+    ms = load_model("humanoidrun").to_struct()
+    # the oracle reads the same bytes: forward kinematics sees 11 links at the expected places
+    st = orc.forward(ms, np.asarray(ms.init_q[:24], np.float32), np.zeros(23, np.float32))
+    assert st.shape == (11, 13) and abs(orc.link_positions(ms, st)[0, 2] - 1.4) < 1e-6
+
+
+def test_host_prng_matches_oracle(lib, orc):
+    from mbd_hip import _capi
+    for seed in (0, 1, 12345, (3 << 32) | 9):
+        k = _capi.prng_key(seed)
+        assert np.array_equal(k, orc.prng_key(seed))
+        for impl in (0, 1):
+            for num in (2, 3, 5):
+                assert np.array_equal(_capi.prng_split(k, num, impl), orc.split(k, num, impl))
+
+
+def test_args_mirror_the_reference_dataclass():
+    from mbd_hip.planners.mbd_planner import Args, apply_recommended
+    a = Args()
+    assert (a.seed, a.env_name, a.Nsample, a.Hsample, a.Ndiffuse) == (0, "ant", 2048, 50, 100)
+    assert (a.temp_sample, a.beta0, a.betaT, a.enable_demo, a.not_render) == (0.1, 1e-4, 1e-2, False, False)
+    a = Args(env_name="humanoidrun")
+    apply_recommended(a)   # mbd_planner.py:54-68: silently N=8192, Ndiffuse=300 unless disabled
+    assert (a.Nsample, a.Ndiffuse, a.temp_sample) == (8192, 300, 0.1)
+    b = Args(env_name="halfcheetah", temp_sample=0.3)
+    apply_recommended(b)
+    assert b.temp_sample == 0.4
+    c = Args(env_name="humanoidrun", disable_recommended_params=True, Nsample=1024)
+    apply_recommended(c)
+    assert c.Nsample == 1024
+
+
+def test_get_env_errors_like_the_reference(lib):
+    from mbd_hip import _capi
+    from mbd_hip.envs import get_env
+    with pytest.raises(ValueError, match="Unknown environment"):
+        get_env("no_such_env")
+    with pytest.raises(ValueError):
+        get_env("pushT")  # in the reference registry, outside the hot-path scope
+    if _capi.device_count() == 0:
+        # no GPU here: the product must fail loudly, never fall back to a CPU path
+        with pytest.raises(_capi.MbdError) as e:
+            get_env("humanoidrun")
+        assert e.value.code == _capi.MBD_ERR_NO_DEVICE
+        with pytest.raises(_capi.MbdError):
+            get_env("car2d")
+
+
+def test_product_does_not_import_the_oracle():
+    pkg = os.path.join(ROOT, "model-based-diffusion_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.lower().replace("checker", ""), f"{f} mentions the oracle"

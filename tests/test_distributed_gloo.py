@@ -1,0 +1,79 @@
+"""The N>1 path on CPU: world_size 2, gloo.  The sharding and the single exchange step are the product's
+(mbd_hip.planners.mbd_planner.shard_bounds / exchange_rewards); the per-shard compute is stood in for by
+the CPU oracle (test infrastructure) because there is no GPU here.  Checks that both ranks finish every
+diffusion step with Ybar bit-identical to the single-process result — the property the multi-GPU
+design rests on."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT, load_model
+
+N, H, ND, STEPS, TEMP, ENV = 32, 8, 20, 3, 0.1, "hopper"
+
+
+def _single(orc, demo=False):
+    from oracle import planner as op
+    m = load_model(ENV)
+    env = op.OracleEnv(orc, ENV, m.to_struct(), init_q=m.init_q)
+    return op.run_diffusion(orc, env, 0, N, H, ND, TEMP, max_steps=STEPS)
+
+
+def _worker(rank, world, port, out):
+    for p in (ROOT, os.path.join(ROOT, "model-based-diffusion_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mbd_hip.planners.mbd_planner import exchange_rewards, shard_bounds
+    from oracle import oracle as orc_mod, planner as op
+    orc = orc_mod.Oracle("f32")
+    m = load_model(ENV)
+    env = op.OracleEnv(orc, ENV, m.to_struct(), init_q=m.init_q)
+    impl = 1
+    rng = orc.prng_key(0)
+    rng, rng_reset = orc.split(rng, 2, impl)
+    state0 = env.reset(rng_reset, impl)
+    sched = orc.schedule(1e-4, 1e-2, ND)
+    rng_exp, _ = orc.split(rng, 2, impl)
+    begin, sh = shard_bounds(N, world, rank)
+    Ybar = np.zeros((H, env.Nu), np.float32)
+    mus = []
+    r = rng_exp
+    for i in range(ND - 1, ND - 1 - STEPS, -1):
+        keys = orc.split(r, 2, impl)
+        r, ks = keys[0], keys[1]
+        Y0s = orc.sample(ks, impl, N, H, env.Nu, 0, N, float(sched[2][i]), Ybar)      # every rank: all N
+        rewss = env.rollout(state0, Y0s[begin:begin + sh])                            # own shard only
+        local = torch.from_numpy(op.mean_h(orc, rewss)).reshape(1, sh)
+        allv = exchange_rewards(local, world)                                         # the ONE collective
+        rews = allv[0].numpy()
+        Ybar, _, _ = orc.score_update(rews, Y0s, Ybar, float(sched[0][i]), float(sched[1][i]),
+                                      float(sched[1][i - 1]), TEMP)
+        mus.append(Ybar)
+    np.save(os.path.join(out, f"mu_{rank}.npy"), np.stack(mus))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_bounds():
+    from mbd_hip.planners.mbd_planner import shard_bounds
+    assert [shard_bounds(1024, 8, r) for r in (0, 3, 7)] == [(0, 128), (384, 128), (896, 128)]
+    with pytest.raises(ValueError):
+        shard_bounds(1000, 3, 0)
+
+
+def test_world2_gloo_matches_single_process_bitwise(orc, tmp_path):
+    ref = _single(orc)["mu_0ts"]
+    port = 29500 + (os.getpid() % 2000)
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mu0 = np.load(tmp_path / "mu_0.npy")
+    mu1 = np.load(tmp_path / "mu_1.npy")
+    assert np.array_equal(mu0, mu1), "ranks disagree"
+    assert np.array_equal(mu0, ref), "sharded result differs from the single-process result"

@@ -1,0 +1,163 @@
+"""Physics oracle (oracle/mbd_oracle_physics.c): invariants that pin the restated positional PBD step
+without Brax, plus the chaos measurement that motivates the bit-exact contract."""
+import math
+import os
+import tempfile
+
+import numpy as np
+import pytest
+
+from conftest import load_model
+
+FREE_BALL = """<mujoco><compiler angle="degree" inertiafromgeom="true"/>
+<default><geom conaffinity="0" contype="0"/></default><option timestep="0.005"/>
+<worldbody><geom conaffinity="1" type="plane" size="5 5 1"/>
+<body name="ball" pos="0 0 {z}"><joint type="free" name="root"/>
+<geom type="sphere" size="0.1" contype="{ct}"/></body></worldbody></mujoco>"""
+
+PENDULUM = """<mujoco><compiler angle="degree" inertiafromgeom="true"/>
+<default><geom conaffinity="0" contype="0"/><joint damping="0" limited="false"/></default>
+<option timestep="0.002"/>
+<custom><numeric name="joint_scale_pos" data="1.0"/><numeric name="joint_scale_ang" data="1.0"/>
+<numeric name="spring_inertia_scale" data="0"/></custom>
+<worldbody><body name="base" pos="0 0 2"><joint type="free"/><geom type="sphere" size="0.3" density="100000"/>
+<body name="arm" pos="0 0 0"><joint type="hinge" axis="0 1 0" pos="0 0 0" name="h" {lim}/>
+<geom type="capsule" fromto="0 0 0 0 0 -0.5" size="0.05"/></body></body></worldbody>
+<actuator><motor joint="h" gear="1" ctrllimited="false"/></actuator></mujoco>"""
+
+
+def _compile(xml, **kw):
+    from mbd_hip import mjcf
+    with tempfile.NamedTemporaryFile("w", suffix=".xml", delete=False) as f:
+        f.write(xml)
+    try:
+        return mjcf.load(f.name, **kw)
+    finally:
+        os.unlink(f.name)
+
+
+def test_free_fall_matches_semi_implicit_euler(orc):
+    m = _compile(FREE_BALL.format(z=5.0, ct=0))
+    ms = m.to_struct()
+    st = orc.forward(ms, m.init_q, np.zeros(6, np.float32))
+    dt, g = 0.005, -9.81
+    z, vz = 5.0, 0.0
+    for _ in range(100):
+        st = orc.substep(ms, st, np.zeros(0, np.float32))
+        vz += g * dt
+        z += vz * dt
+    # PBD re-derives v = (p - p_prev)/dt every substep: f32 round-off of p (ulp 5e-7 at z~5) times 1/dt
+    # random-walks the velocity, so the match is to ~1e-3, not to round-off
+    assert abs(st[0, 2] - z) < 3e-3 and abs(st[0, 9] - vz) < 2e-2
+    assert np.allclose(st[0, 3:7], [1, 0, 0, 0]) and np.allclose(st[0, :2], 0)
+
+
+def test_sphere_rests_on_the_plane(orc):
+    m = _compile(FREE_BALL.format(z=0.3, ct=1))
+    ms = m.to_struct()
+    st = orc.forward(ms, m.init_q, np.zeros(6, np.float32))
+    for _ in range(400):
+        st = orc.substep(ms, st, np.zeros(0, np.float32))
+    assert abs(st[0, 2] - 0.1) < 2e-3          # centre at z = radius
+    assert np.abs(st[0, 7:]).max() < 0.06       # at rest up to one substep of gravity
+
+
+def test_hinge_keeps_its_anchor_and_axis(orc):
+    """A hinged rod on a heavy free base, both in free fall (no gravity in the falling frame): the rod
+    keeps swinging about the hinge axis only, and its anchor stays on the base."""
+    m = _compile(PENDULUM.format(lim=""))
+    ms = m.to_struct()
+    qd = np.zeros(7, np.float32)
+    qd[6] = 2.0  # hinge angular velocity
+    st = orc.forward(ms, m.init_q, qd)
+    com = np.asarray(m.fields["com"][1], float)
+    for _ in range(500):
+        st = orc.substep(ms, st, np.zeros(1, np.float32))
+        anchor_c = st[1, :3] - _rot(st[1, 3:7], com)      # hinge anchor = link-frame origin of the rod
+        assert np.linalg.norm(anchor_c - st[0, :3]) < 2e-3
+        ang = orc.joint_angles(ms, st)[1]
+        assert abs(ang[1]) < 2e-3 and abs(ang[2]) < 2e-3   # no rotation out of the hinge axis
+    assert orc.joint_angles(ms, st)[1, 0] > 1.0            # ~2 rad/s for 1 s, damped a little by the solver
+
+
+def _rot(q, v):
+    w, x, y, z = [float(t) for t in q]
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                  [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                  [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+    return R @ np.asarray(v, float)
+
+
+def test_joint_limit_clamps(orc):
+    m = _compile(PENDULUM.format(lim='limited="true" range="-20 20"'))
+    ms = m.to_struct()
+    st = orc.forward(ms, m.init_q, np.zeros(7, np.float32))
+    worst = 0.0
+    for _ in range(600):
+        st = orc.substep(ms, st, np.array([3.0], np.float32))  # constant torque pushes into the limit
+        worst = max(worst, abs(orc.joint_angles(ms, st)[1, 0]))
+    assert worst < math.radians(20) + 0.08      # soft (scaled) projection keeps it near the limit
+    assert worst > math.radians(15)              # the torque does drive it to the limit
+
+
+def test_humanoid_zero_action_feet_rest_on_floor(orc):
+    m = load_model("humanoidrun")
+    ms = m.to_struct()
+    st = orc.forward(ms, m.init_q, np.zeros(m.qd_size(), np.float32))
+    pos0 = orc.link_positions(ms, st)
+    assert np.allclose(pos0[0], [0, 0, 1.4]) and abs(pos0[4, 2] - 0.532) < 1e-3
+    zero = np.zeros(17, np.float32)
+    for _ in range(12):
+        st, r = orc.env_step(ms, st, zero)
+    pos = orc.link_positions(ms, st)
+    # shin origin is 0.35 above the foot sphere centre (radius 0.075): rests at 0.425
+    assert abs(pos[4, 2] - 0.425) < 0.01 and abs(pos[6, 2] - 0.425) < 0.01
+    assert np.isfinite(st).all() and abs(pos[0, 1]) < 1e-3       # left/right symmetric fall
+    # reward = x - clip(|z - 1.3|) - 0.1 |y| of the torso origin (humanoidrun.py:46-51)
+    assert abs(r - (pos[0, 0] - min(abs(pos[0, 2] - 1.3), 1.0) - 0.1 * abs(pos[0, 1]))) < 1e-6
+
+
+@pytest.mark.parametrize("name", ["humanoidrun", "humanoidtrack", "hopper", "halfcheetah"])
+def test_rollouts_stay_finite_and_actions_saturate(orc, name):
+    m = load_model(name)
+    ms = m.to_struct()
+    st = orc.forward(ms, m.init_q, np.zeros(m.qd_size(), np.float32))
+    g = np.random.default_rng(0)
+    us = np.clip(g.normal(size=(6, 50, m.act_size())), -1, 1).astype(np.float32)
+    rew, fin = orc.rollout(ms, st, us, want_final=True)
+    assert np.isfinite(rew).all() and np.isfinite(fin).all()
+    assert np.allclose(np.linalg.norm(fin[:, :, 3:7], axis=-1), 1.0, atol=1e-5)
+    if name.startswith("humanoid"):
+        # ctrlrange +-0.4 (humanoidrun.xml:6): actions beyond it saturate inside the actuator model
+        big = (np.sign(us) * np.maximum(np.abs(us), 0.4)).astype(np.float32)
+        sat = np.clip(big, -0.4, 0.4)
+        assert np.array_equal(orc.rollout(ms, st, big), orc.rollout(ms, st, sat))
+
+
+def test_humanoidtrack_reward_is_lagged(orc):
+    """humanoidtrack.py:78 passes the INCOMING state to _get_reward: reward[0] is the reset state's."""
+    m = load_model("humanoidtrack")
+    ms = m.to_struct()
+    st = orc.forward(ms, m.init_q, np.zeros(m.qd_size(), np.float32))
+    g = np.random.default_rng(1)
+    us = g.uniform(-1, 1, (4, 5, 17)).astype(np.float32)
+    rew = orc.rollout(ms, st, us)
+    # torso at z=1.4, v=0: 1 - |0 - 1.6| - |1.4 - 1.3| - 0 = -0.7
+    assert np.allclose(rew[:, 0], -0.7, atol=1e-6) and len(set(rew[:, 0].tolist())) == 1
+    assert len(set(rew[:, 2].tolist())) > 1
+
+
+def test_chaos_amplification(orc, orc64):
+    """Why parity is bit-exact and not 'within 1e-5': the same code in f32 and f64 drifts by more than
+    1e-5 (relative) in reward over a 50-step contact-rich rollout, i.e. no two correct-but-differently-
+    rounded implementations can be compared through a tolerance at full horizon."""
+    m = load_model("humanoidrun")
+    ms = m.to_struct()
+    g = np.random.default_rng(0)
+    st = orc.forward(ms, m.init_q + g.uniform(-0.01, 0.01, 24).astype(np.float32),
+                     g.uniform(-0.01, 0.01, 23).astype(np.float32))
+    us = np.clip(g.normal(size=(48, 50, 17)) * 0.6, -1, 1).astype(np.float32)
+    r32, r64 = orc.rollout(ms, st, us), orc64.rollout(ms, st, us)
+    err = np.abs(r32 - r64)
+    assert err[:, 0].max() < 5e-6            # one control step: round-off only
+    assert err[:, -1].max() > 1e-4           # 350 substeps later: amplified by orders of magnitude
