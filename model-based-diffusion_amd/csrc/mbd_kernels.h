@@ -91,18 +91,19 @@ __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp,
   return f;
 }
 
+// one angular positional correction (rotate child by +e, parent by -e): I^-1 e * |e|^2 /
+// (e.I_p^-1 e + e.I_c^-1 e) — one division, no square root
 template <bool ISO>
 __device__ __forceinline__ void ang_correct(v3 e, const Inert<ISO>& ip, q4 Pr, const Inert<ISO>& ic, q4 Cr,
                                             float sc, v3& dth_p, v3& dth_c) {
-  float th = fsqrt(dot(e, e));
-  float inv = 1.0f / (th + 1e-10f);
-  v3 n = scale(e, inv);
-  v3 inp = iinv<ISO>(ip, Pr, n), inc = iinv<ISO>(ic, Cr, n);
-  float wp = dot(n, inp), wc = dot(n, inc);
-  float dlam = (th / (wp + wc + 1e-10f)) * sc;
-  dth_c = axpy(dlam, inc, dth_c);
-  dth_p = axpy(-dlam, inp, dth_p);
+  v3 inp = iinv<ISO>(ip, Pr, e), inc = iinv<ISO>(ic, Cr, e);
+  float den = dot(e, inp) + dot(e, inc);
+  float g = (dot(e, e) / (den + 1e-20f)) * sc;
+  dth_c = axpy(g, inc, dth_c);
+  dth_p = axpy(-g, inp, dth_p);
 }
+// contact normal = +z of the floor plane
+__device__ __forceinline__ v3 crossz(v3 a) { return v3{a.y, -a.x, 0.0f}; }
 
 // LPS   lanes per candidate (power of two >= n_links)
 // ISO   model-wide isotropic inverse inertia (spring_inertia_scale = 1 models: the humanoid)
@@ -143,7 +144,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
   jc.ac_pos = mk3(M->ac_pos[l][0], M->ac_pos[l][1], M->ac_pos[l][2]);
   jc.ap_rot = q4{M->ap_rot[l][0], M->ap_rot[l][1], M->ap_rot[l][2], M->ap_rot[l][3]};
   jc.ac_rot = q4{M->ac_rot[l][0], M->ac_rot[l][1], M->ac_rot[l][2], M->ac_rot[l][3]};
-  const float ang_damp = M->ang_damp[l], vel_damp = M->vel_damp[l];
+  // non-joint lanes (free root, padding) are masked through their scalars: every contribution they
+  // compute is then an exact zero
+  const float ang_damp = is_joint ? M->ang_damp[l] : 0.0f, vel_damp = is_joint ? M->vel_damp[l] : 0.0f;
+  const int nr_eff = is_joint ? nr : -1;
+  const int zero_lane = M->n_rot[0] < 0 ? base : (L < LPS ? base + L : -1);  // a lane contributing zeros
   float lim_lo[3], lim_hi[3], stiff[3], damp[3];
   v3 saxis[3];
   int act_rot[3], act_sl[3];
@@ -178,6 +183,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         ++nc;
       }
   }
+  int child_src[MAXCH];  // lane to pull child c's contribution from (a zero lane when there is none)
+#pragma unroll
+  for (int c = 0; c < MAXCH; ++c) child_src[c] = child_lane[c] >= 0 ? child_lane[c] : (zero_lane >= 0 ? zero_lane : lane);
   v3 col_pos[MAXCOL];
   float col_rad[MAXCOL];
   bool col_has[MAXCOL];
@@ -204,10 +212,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
     if (M->track_link[k] == l && link_ok) track_k = k;
   const v3 com = mk3(M->com[l][0], M->com[l][1], M->com[l][2]);
   const float dt = M->dt, inv_dt = 1.0f / M->dt, vel_fac = M->vel_fac, ang_fac = M->ang_fac;
-  const float js_pos = M->joint_scale_pos, js_ang = M->joint_scale_ang, coll_scale = M->collide_scale;
+  const float js_pos = is_joint ? M->joint_scale_pos : 0.0f, js_ang = is_joint ? M->joint_scale_ang : 0.0f;
+  const float coll_scale = M->collide_scale, invm_sum = ip.inv_mass + ic.inv_mass;
   const float mu = M->friction, elast = M->elasticity;
   const v3 grav = mk3(M->gravity[0], M->gravity[1], M->gravity[2]);
-  const v3 nrm = mk3(0.0f, 0.0f, 1.0f);
   const int rkind = M->reward_kind;
   const float rp0 = M->reward_params[0], rp1 = M->reward_params[1];
   const float dt_ctrl = M->dt * (float)nfr;
@@ -267,7 +275,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         auto torque = [&](int k, v3 ax, float ang) {
           float qdk = dot(rel_w, ax);
           float fk = ffma(-stiff[k], ang, ffma(-damp[k], qdk, tau[k]));
-          fk = k < nr ? fk : 0.0f;
+          fk = k < nr_eff ? fk : 0.0f;
           T = axpy(fk, ax, T);
         };
         torque(0, f.Xp, f.ang0);
@@ -277,7 +285,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             v3 s = rot(saxis[k], f.aprot);
-            F = axpy(k < ns ? tau_sl[k] : 0.0f, s, F);
+            F = axpy(k < ns && is_joint ? tau_sl[k] : 0.0f, s, F);
             float cf = k < ns ? -dot(rel_v, s) : 0.0f;
             rel_v = axpy(cf, s, rel_v);
           }
@@ -288,17 +296,18 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         fc_w = iinv<ISO>(ic, r, add(T, cross(rc, F)));
         fp_v = scale(F, -ip.inv_mass);
         fp_w = scale(iinv<ISO>(ip, Pr, add(T, cross(rp, F))), -1.0f);
-        if (!is_joint) { fc_v = fc_w = fp_v = fp_w = mk3(0, 0, 0); }
       }
       // ---- (2) integrator.integrate_xdd -------------------------------------------------------------
       v3 av = fc_v, aw = fc_w;
 #pragma unroll
       for (int c = 0; c < MAXCH; ++c) {
-        const bool has = child_lane[c] >= 0;
-        const int src = has ? child_lane[c] : lane;
-        v3 cv = shfl3(fp_v, src), cw = shfl3(fp_w, src);
-        av = sel3(has, add(av, cv), av);
-        aw = sel3(has, add(aw, cw), aw);
+        v3 cv = shfl3(fp_v, child_src[c]), cw = shfl3(fp_w, child_src[c]);
+        if (zero_lane < 0) {  // no zero lane in this model: mask missing children (wave-uniform branch)
+          cv = sel3(child_lane[c] >= 0, cv, mk3(0, 0, 0));
+          cw = sel3(child_lane[c] >= 0, cw, mk3(0, 0, 0));
+        }
+        av = add(av, cv);
+        aw = add(aw, cw);
       }
       v = mk3(ffma(av.x + grav.x, dt, vel_fac * v.x), ffma(av.y + grav.y, dt, vel_fac * v.y),
               ffma(av.z + grav.z, dt, vel_fac * v.z));
@@ -324,14 +333,12 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           }
         }
         v3 rc = sub(f.ac, p), rp = sub(f.ap, Pp);
-        float c = fsqrt(dot(d, d));
-        float inv = 1.0f / (c + 1e-10f);
-        v3 n = scale(d, inv);
-        v3 cp = cross(rp, n), cc = cross(rc, n);
+        float c2 = dot(d, d);
+        v3 cp = cross(rp, d), cc = cross(rc, d);
         v3 icp = iinv<ISO>(ip, Pr, cp), icc = iinv<ISO>(ic, r, cc);
-        float wp = ip.inv_mass + dot(cp, icp), wc = ic.inv_mass + dot(cc, icc);
-        float dlam = (c / (wp + wc)) * js_pos;
-        v3 Pimp = scale(n, dlam);
+        float den = ffma(invm_sum, c2, dot(cp, icp) + dot(cc, icc));
+        float g = (c2 / (den + 1e-20f)) * js_pos;
+        v3 Pimp = scale(d, g);
         dc_p = scale(Pimp, ic.inv_mass);
         dc_th = iinv<ISO>(ic, r, cross(rc, Pimp));
         dp_p = scale(Pimp, -ip.inv_mass);
@@ -339,28 +346,29 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         // angular alignment by joint type (1 hinge: Xc || Xp; 2 hinges: Yc _|_ Xp; 3: free)
         v3 A = sel3(nr == 1, f.Xc, f.Xp);
         v3 Bv = sel3(nr == 1, f.Xp, f.Yc);
-        float sc = nr == 1 ? 1.0f : (nr == 2 ? dot(f.Xp, f.Yc) : 0.0f);
+        float sc = nr_eff == 1 ? 1.0f : (nr_eff == 2 ? dot(f.Xp, f.Yc) : 0.0f);
         v3 e = scale(cross(A, Bv), sc);
         ang_correct<ISO>(e, ip, Pr, ic, r, js_ang, dp_th, dc_th);
         auto limit = [&](int k, v3 ax, float a) {
           float viol = a < lim_lo[k] ? a - lim_lo[k] : (a > lim_hi[k] ? a - lim_hi[k] : 0.0f);
-          viol = k < nr ? viol : 0.0f;
+          viol = k < nr_eff ? viol : 0.0f;
           ang_correct<ISO>(scale(ax, -viol), ip, Pr, ic, r, js_ang, dp_th, dc_th);
         };
         limit(0, f.Xp, f.ang0);
         limit(1, f.ax1, f.ang1);
         limit(2, f.Zc, f.ang2);
-        if (!is_joint) { dc_p = dc_th = dp_p = dp_th = mk3(0, 0, 0); }
       }
       {
         v3 dp = dc_p, dth = dc_th;
 #pragma unroll
         for (int c = 0; c < MAXCH; ++c) {
-          const bool has = child_lane[c] >= 0;
-          const int src = has ? child_lane[c] : lane;
-          v3 cp = shfl3(dp_p, src), cth = shfl3(dp_th, src);
-          dp = sel3(has, add(dp, cp), dp);
-          dth = sel3(has, add(dth, cth), dth);
+          v3 cp = shfl3(dp_p, child_src[c]), cth = shfl3(dp_th, child_src[c]);
+          if (zero_lane < 0) {
+            cp = sel3(child_lane[c] >= 0, cp, mk3(0, 0, 0));
+            cth = sel3(child_lane[c] >= 0, cth, mk3(0, 0, 0));
+          }
+          dp = add(dp, cp);
+          dth = add(dth, cth);
         }
         p = add(p, dp);
         r = qrotvec(r, dth);
@@ -378,23 +386,22 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           bool active = col_has[j] && pen > 0.0f;
           v3 pos = mk3(ctr.x, ctr.y, ctr.z - ffma(-0.5f, pen, col_rad[j]));
           v3 rc = sub(pos, p);
-          v3 cn = cross(rc, nrm);
+          v3 cn = crossz(rc);
           v3 icn = iinv<ISO>(ic, r, cn);
           float wn = ic.inv_mass + dot(cn, icn);
           float dlam = (pen / wn) * coll_scale;
-          v3 Pimp = scale(nrm, dlam);
+          v3 Pimp = mk3(0.0f, 0.0f, dlam);
           v3 rl = irot(rc, r);
           v3 pprev = add(p_prev, rot(rl, r_prev));
           v3 dx = sub(pos, pprev);
-          dx = axpy(-dot(dx, nrm), nrm, dx);
-          float ct = fsqrt(dot(dx, dx));
-          float inv = 1.0f / (ct + 1e-10f);
-          v3 nt = scale(dx, inv);
-          v3 cnt = cross(rc, nt);
+          dx.z = 0.0f;
+          float ct2 = ffma(dx.x, dx.x, dx.y * dx.y);
+          v3 cnt = cross(rc, dx);
           v3 icnt = iinv<ISO>(ic, r, cnt);
-          float wt = ic.inv_mass + dot(cnt, icnt);
-          float dlamt = -(ct / wt);
-          Pimp = sel3(fabs_(dlamt) < mu * dlam, axpy(dlamt, nt, Pimp), Pimp);
+          float dent = ffma(ic.inv_mass, ct2, dot(cnt, icnt));
+          float gt = ct2 / (dent + 1e-20f);
+          float lim = mu * dlam;
+          Pimp = sel3((ct2 * gt) * gt < lim * lim, axpy(-gt, dx, Pimp), Pimp);
           v3 ncd_p = axpy(ic.inv_mass, Pimp, cd_p);
           v3 ncd_th = add(cd_th, iinv<ISO>(ic, r, cross(rc, Pimp)));
           cd_p = sel3(active, ncd_p, cd_p);
@@ -420,12 +427,12 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         v3 rc = sub(con_pos[j], p);
         v3 vpt = add(v, cross(w, rc));
         v3 vprev = add(v_old, cross(w_old, rc));
-        float vn = dot(vpt, nrm), vn_prev = dot(vprev, nrm);
-        v3 vt = axpy(-vn, nrm, vpt);
-        float vtn = fsqrt(dot(vt, vt));
+        float vn = vpt.z, vn_prev = vprev.z;
+        v3 vt = mk3(vpt.x, vpt.y, 0.0f);
+        float vtn = fsqrt(ffma(vt.x, vt.x, vt.y * vt.y));
         float inv = 1.0f / (vtn + 1e-10f);
         v3 dir = scale(vt, inv);
-        v3 cn = cross(rc, nrm), cdv = cross(rc, dir);
+        v3 cn = crossz(rc), cdv = cross(rc, dir);
         v3 icn = iinv<ISO>(ic, r, cn), icd = iinv<ISO>(ic, r, cdv);
         float wn = ic.inv_mass + dot(cn, icn), wt = ic.inv_mass + dot(cdv, icd);
         float rest = -elast * vn_prev;
@@ -433,7 +440,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         float jt_max = (mu * con_dlam[j]) * inv_dt;
         float dvt = fmin_(jt_max * wt, vtn);
         float jn = dvn / wn, jt = -(dvt / wt);
-        v3 Pimp = axpy(jt, dir, scale(nrm, jn));
+        v3 Pimp = scale(dir, jt);
+        Pimp.z = Pimp.z + jn;
         v3 nv = axpy(ic.inv_mass, Pimp, v);
         v3 nw = add(w, iinv<ISO>(ic, r, cross(rc, Pimp)));
         v = sel3(con_act[j], nv, v);

@@ -23,7 +23,7 @@ struct q4 {
 
 MBD_HD float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 MBD_HD float fsqrt(float x) { return __builtin_sqrtf(x); }
-MBD_HD float fabs_(float x) { return x < 0.0f ? -x : x; }
+MBD_HD float fabs_(float x) { return __builtin_fabsf(x); }
 MBD_HD float fmin_(float a, float b) { return a < b ? a : b; }
 MBD_HD float fmax_(float a, float b) { return a > b ? a : b; }
 MBD_HD float fclip(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }

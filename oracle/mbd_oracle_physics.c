@@ -95,20 +95,23 @@ static void joint_frames(const mbd_model_t* m, int l, const xf_t* P, const xf_t*
 }
 
 /* one angular positional correction: rotate child by +e, parent by -e, split by angular inverse
- * masses. e: rotation-vector error (world). accumulates into dth_c / dth_p. */
+ * masses. e: rotation-vector error (world). With n = e/|e|, w = n.I^-1 n and lambda = |e|/(wp+wc) the
+ * correction lambda * I^-1 n equals I^-1 e * |e|^2 / (e.I_p^-1 e + e.I_c^-1 e): one division, no
+ * square root. accumulates into dth_c / dth_p. */
 static void ang_correct(const real e[3], const inert_t* ip, const inert_t* ic, real scale, real dth_p[3],
                         real dth_c[3]) {
-  real th = sp_sqrt(sp_dot3(e, e));
-  real inv = R(1) / (th + R(1e-10));
-  real n[3], inp[3], inc[3];
-  sp_scale3(e, inv, n);
-  iinv_apply(ip, n, inp);
-  iinv_apply(ic, n, inc);
-  real wp = sp_dot3(n, inp), wc = sp_dot3(n, inc);
-  real dlam = (th / (wp + wc + R(1e-10))) * scale;
-  sp_axpy3(dlam, inc, dth_c);
-  sp_axpy3(-dlam, inp, dth_p);
+  real inp[3], inc[3];
+  iinv_apply(ip, e, inp);
+  iinv_apply(ic, e, inc);
+  real den = sp_dot3(e, inp) + sp_dot3(e, inc);
+  real g = (sp_dot3(e, e) / (den + R(1e-20))) * scale;
+  sp_axpy3(g, inc, dth_c);
+  sp_axpy3(-g, inp, dth_p);
 }
+
+/* the contact normal is the +z axis of the floor plane: specialised vector helpers (same roundings
+ * as the generic ones with n = (0,0,1), minus the multiplications by zero) */
+static inline void crossz(const real a[3], real o[3]) { o[0] = a[1]; o[1] = -a[0]; o[2] = R(0); }
 
 typedef struct {
   int active;
@@ -216,16 +219,16 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
       sp_axpy3(-sp_dot3(d, s), s, d);
     }
     sp_sub3(f.ac, x[l].p, rc); sp_sub3(f.ap, P->p, rp);
-    real c = sp_sqrt(sp_dot3(d, d));
-    real inv = R(1) / (c + R(1e-10));
-    real n[3], cp[3], cc[3], icp[3], icc[3];
-    sp_scale3(d, inv, n);
-    sp_cross3(rp, n, cp); sp_cross3(rc, n, cc);
+    /* with n = d/|d| and lambda = |d|/(wp+wc): P = lambda n = d * |d|^2 / (|d|^2 (1/m_p + 1/m_c) +
+     * (rp x d).I_p^-1 (rp x d) + (rc x d).I_c^-1 (rc x d)) — one division, no square root */
+    real c2 = sp_dot3(d, d);
+    real cp[3], cc[3], icp[3], icc[3];
+    sp_cross3(rp, d, cp); sp_cross3(rc, d, cc);
     iinv_apply(ip, cp, icp); iinv_apply(ic, cc, icc);
-    real wp = ip->inv_mass + sp_dot3(cp, icp), wc = ic->inv_mass + sp_dot3(cc, icc);
-    real dlam = (c / (wp + wc)) * R(m->joint_scale_pos);
+    real den = sp_fma(ip->inv_mass + ic->inv_mass, c2, sp_dot3(cp, icp) + sp_dot3(cc, icc));
+    real g = (c2 / (den + R(1e-20))) * R(m->joint_scale_pos);
     real Pimp[3], mom[3], t[3];
-    sp_scale3(n, dlam, Pimp);
+    sp_scale3(d, g, Pimp);
     sp_scale3(Pimp, ic->inv_mass, dc_p[l]);
     sp_cross3(rc, Pimp, mom); iinv_apply(ic, mom, dc_th[l]);
     sp_scale3(Pimp, -ip->inv_mass, dp_p[l]);
@@ -271,7 +274,6 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
   int has_col[MBD_MAX_LINKS];
   memset(cd_p, 0, sizeof(cd_p)); memset(cd_th, 0, sizeof(cd_th)); memset(has_col, 0, sizeof(has_col));
   const real mu = R(m->friction);
-  const real nrm[3] = {0, 0, 1};
   for (int k = 0; k < m->n_col; ++k) {
     const int l = m->col_link[k];
     has_col[l] = 1;
@@ -285,26 +287,26 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_set3(con[k].pos, ctr[0], ctr[1], ctr[2] - sp_fma(R(-0.5), pen, rad));
     real rc[3], cn[3], icn[3];
     sp_sub3(con[k].pos, x[l].p, rc);
-    sp_cross3(rc, nrm, cn); iinv_apply(&in[l], cn, icn);
+    crossz(rc, cn); iinv_apply(&in[l], cn, icn);
     real w = in[l].inv_mass + sp_dot3(cn, icn);
     real dlam = (pen / w) * R(m->collide_scale);
     con[k].dlam = dlam;
-    real Pimp[3], mom[3];
-    sp_scale3(nrm, dlam, Pimp);
+    real Pimp[3] = {0, 0, dlam}, mom[3];
     /* static friction: undo the tangential motion of the contact point over this substep if the
-     * required tangential lambda stays inside the friction cone */
+     * required tangential lambda stays inside the friction cone. With t = dx_t/|dx_t|:
+     * lambda_t t = -dx_t * |dx_t|^2 / (|dx_t|^2/m + (rc x dx_t).I^-1 (rc x dx_t)); the cone test
+     * |lambda_t| < mu lambda_n is done on squares — one division, no square root */
     real rl[3], pprev[3], dx[3];
     sp_irot(rc, x[l].r, rl); sp_rot(rl, x_prev[l].r, t); sp_add3(x_prev[l].p, t, pprev);
     sp_sub3(con[k].pos, pprev, dx);
-    sp_axpy3(-sp_dot3(dx, nrm), nrm, dx);
-    real ct = sp_sqrt(sp_dot3(dx, dx));
-    real inv = R(1) / (ct + R(1e-10));
-    real nt[3], cnt[3], icnt[3];
-    sp_scale3(dx, inv, nt);
-    sp_cross3(rc, nt, cnt); iinv_apply(&in[l], cnt, icnt);
-    real wt = in[l].inv_mass + sp_dot3(cnt, icnt);
-    real dlamt = -(ct / wt);
-    if (sp_abs(dlamt) < mu * dlam) sp_axpy3(dlamt, nt, Pimp);
+    dx[2] = R(0);
+    real ct2 = sp_fma(dx[0], dx[0], dx[1] * dx[1]);
+    real cnt[3], icnt[3];
+    sp_cross3(rc, dx, cnt); iinv_apply(&in[l], cnt, icnt);
+    real dent = sp_fma(in[l].inv_mass, ct2, sp_dot3(cnt, icnt));
+    real gt = ct2 / (dent + R(1e-20));
+    real lim = mu * dlam;
+    if ((ct2 * gt) * gt < lim * lim) sp_axpy3(-gt, dx, Pimp);
     sp_axpy3(in[l].inv_mass, Pimp, cd_p[l]);
     sp_cross3(rc, Pimp, mom); iinv_apply(&in[l], mom, t); sp_add3(cd_th[l], t, cd_th[l]);
   }
@@ -331,15 +333,13 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_sub3(con[k].pos, x[l].p, rc);
     sp_cross3(xd[l].w, rc, t); sp_add3(xd[l].v, t, vpt);
     sp_cross3(xd_prev[l].w, rc, t); sp_add3(xd_prev[l].v, t, vprev);
-    real vn = sp_dot3(vpt, nrm), vn_prev = sp_dot3(vprev, nrm);
-    real vt[3];
-    sp_copy3(vpt, vt);
-    sp_axpy3(-vn, nrm, vt);
-    real vtn = sp_sqrt(sp_dot3(vt, vt));
+    real vn = vpt[2], vn_prev = vprev[2];
+    real vt[3] = {vpt[0], vpt[1], R(0)};
+    real vtn = sp_sqrt(sp_fma(vt[0], vt[0], vt[1] * vt[1]));
     real inv = R(1) / (vtn + R(1e-10));
     real dir[3], cn[3], icn[3], cdv[3], icd[3];
     sp_scale3(vt, inv, dir);
-    sp_cross3(rc, nrm, cn); iinv_apply(&in[l], cn, icn);
+    crossz(rc, cn); iinv_apply(&in[l], cn, icn);
     sp_cross3(rc, dir, cdv); iinv_apply(&in[l], cdv, icd);
     real wn = in[l].inv_mass + sp_dot3(cn, icn), wt = in[l].inv_mass + sp_dot3(cdv, icd);
     real rest = -R(m->elasticity) * vn_prev;
@@ -348,8 +348,8 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     real dvt = sp_min(jt_max * wt, vtn);
     real jn = dvn / wn, jt = -(dvt / wt);
     real Pimp[3];
-    sp_scale3(nrm, jn, Pimp);
-    sp_axpy3(jt, dir, Pimp);
+    sp_scale3(dir, jt, Pimp);
+    Pimp[2] = Pimp[2] + jn;
     sp_axpy3(in[l].inv_mass, Pimp, xd[l].v);
     real mom[3];
     sp_cross3(rc, Pimp, mom); iinv_apply(&in[l], mom, t); sp_add3(xd[l].w, t, xd[l].w);

@@ -32,7 +32,7 @@ static inline real sp_fma(real a, real b, real c) {
 static inline real sp_sqrt(real x) {
   return sizeof(real) == 4 ? (real)__builtin_sqrtf((float)x) : (real)__builtin_sqrt((double)x);
 }
-static inline real sp_abs(real x) { return x < R(0) ? -x : x; }
+static inline real sp_abs(real x) { return sizeof(real) == 4 ? (real)__builtin_fabsf((float)x) : (real)__builtin_fabs((double)x); }
 static inline real sp_min(real a, real b) { return a < b ? a : b; }
 static inline real sp_max(real a, real b) { return a > b ? a : b; }
 static inline real sp_clip(real v, real lo, real hi) { return v < lo ? lo : (v > hi ? hi : v); }
