@@ -83,10 +83,11 @@ __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp,
   axes3 A = qaxes(f.aprot), C = qaxes(acrot);
   f.Xp = A.X; f.Xc = C.X; f.Yc = C.Y; f.Zc = C.Z;
   f.ang0 = atan2_(-dot(C.Z, A.Y), dot(C.Z, A.Z));
-  f.ang1 = asin_(fclip(dot(C.Z, A.X), -1.0f, 1.0f));
+  float cb;  // cos of the middle angle = |Zc x Xp|
+  f.ang1 = asin_c(fclip(dot(C.Z, A.X), -1.0f, 1.0f), &cb);
   f.ang2 = atan2_(-dot(C.Y, A.X), dot(C.X, A.X));
   v3 n = cross(C.Z, A.X);
-  float inv = 1.0f / (fsqrt(dot(n, n)) + 1e-10f);
+  float inv = 1.0f / (cb + 1e-10f);
   f.ax1 = scale(n, inv);
   return f;
 }
@@ -204,9 +205,6 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         ++nc;
       }
   }
-  bool any_col = false;
-#pragma unroll
-  for (int j = 0; j < MAXCOL; ++j) any_col = any_col || col_has[j];
   int track_k = -1;
   for (int k = 0; k < K; ++k)
     if (M->track_link[k] == l && link_ok) track_k = k;
@@ -371,7 +369,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           dth = add(dth, cth);
         }
         p = add(p, dp);
-        r = qrotvec(r, dth);
+        r = qrotvec_raw(r, dth);  // renormalised at the end of stage (4)
       }
       // ---- (4) sphere-plane contacts + collisions.resolve_position ---------------------------------
       v3 con_pos[MAXCOL];
@@ -408,10 +406,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           cd_th = sel3(active, ncd_th, cd_th);
           con_pos[j] = pos; con_dlam[j] = dlam; con_act[j] = active;
         }
-        v3 np = add(p, cd_p);
-        q4 nr_ = qrotvec(r, cd_th);
-        p = sel3(any_col, np, p);
-        r = sel4(any_col, nr_, r);
+        p = add(p, cd_p);  // zero corrections on links without colliders
+        r = qrotvec(r, cd_th);
       }
       // ---- (5) integrator.project_xd ------------------------------------------------------------------
       const v3 v_old = v, w_old = w;
@@ -687,9 +683,19 @@ __global__ __launch_bounds__(64) void wmean_kernel(const float* __restrict__ wei
                                                    float* __restrict__ Ybar_im1) {
   const int e = blockIdx.x * 64 + threadIdx.x;
   if (e >= HNu) return;
+  // sequential fma over n (the canonical order); loads are independent of the accumulator, so keep 32 of
+  // them in flight per lane to cover the L2/HBM latency of the 3.5 MB stream
   float acc = 0.0f;
-#pragma unroll 8
-  for (int n = 0; n < N; ++n) acc = ffma(weights[n], Y0s[(size_t)n * HNu + e], acc);
+  const float* __restrict__ col = Y0s + e;
+  int n = 0;
+  for (; n + 32 <= N; n += 32) {
+    float y[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) y[k] = col[(size_t)(n + k) * HNu];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc = ffma(weights[n + k], y[k], acc);
+  }
+  for (; n < N; ++n) acc = ffma(weights[n], col[(size_t)n * HNu], acc);
   float out = acc;
   if (literal) {
     const float sab = fsqrt(alpha_bar_i);

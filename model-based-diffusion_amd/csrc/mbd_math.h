@@ -65,16 +65,18 @@ MBD_HD q4 qnormalize(q4 q) {
   float inv = 1.0f / fsqrt(n2);
   return q4{q.w * inv, q.x * inv, q.y * inv, q.z * inv};
 }
-// normalize(q + 0.5 (0,th) (x) q)
-MBD_HD q4 qrotvec(q4 q, v3 th) {
+// q + 0.5 (0,th) (x) q, not renormalised
+MBD_HD q4 qrotvec_raw(q4 q, v3 th) {
   float hx = 0.5f * th.x, hy = 0.5f * th.y, hz = 0.5f * th.z;
   q4 o;
   o.w = ffma(-hz, q.z, ffma(-hy, q.y, ffma(-hx, q.x, q.w)));
   o.x = ffma(-hz, q.y, ffma(hy, q.z, ffma(hx, q.w, q.x)));
   o.y = ffma(hz, q.x, ffma(hy, q.w, ffma(-hx, q.z, q.y)));
   o.z = ffma(hz, q.w, ffma(-hy, q.x, ffma(hx, q.y, q.z)));
-  return qnormalize(o);
+  return o;
 }
+// normalize(q + 0.5 (0,th) (x) q)
+MBD_HD q4 qrotvec(q4 q, v3 th) { return qnormalize(qrotvec_raw(q, th)); }
 struct axes3 {
   v3 X, Y, Z;
 };
@@ -109,9 +111,11 @@ MBD_HD float atan2_(float y, float x) {
   r = x < 0.0f ? 3.14159265358979323846f - r : r;
   return y < 0.0f ? -r : r;
 }
-MBD_HD float asin_(float v) {
+MBD_HD float asin_c(float v, float* cos_out) {  // also returns sqrt(1 - v^2)
   float c2 = ffma(-v, v, 1.0f);
-  return atan2_(v, fsqrt(c2 < 0.0f ? 0.0f : c2));
+  float c = fsqrt(c2 < 0.0f ? 0.0f : c2);
+  *cos_out = c;
+  return atan2_(v, c);
 }
 MBD_HD void sincos_(float x, float* s_out, float* c_out) {
   float k = __builtin_rintf(x * 0.63661977236758134308f);

@@ -84,13 +84,14 @@ static void joint_frames(const mbd_model_t* m, int l, const xf_t* P, const xf_t*
   sp_qaxes(f->acrot, f->Xc, f->Yc, f->Zc);
   /* R_rel = Rx(a) Ry(b) Rz(c), columns = child axes in the parent joint frame */
   f->ang[0] = sp_atan2(-sp_dot3(f->Zc, f->Yp), sp_dot3(f->Zc, f->Zp));
-  f->ang[1] = sp_asin(sp_clip(sp_dot3(f->Zc, f->Xp), R(-1), R(1)));
+  real cb; /* cos of the middle angle = |Zc x Xp| */
+  f->ang[1] = sp_asin_c(sp_clip(sp_dot3(f->Zc, f->Xp), R(-1), R(1)), &cb);
   f->ang[2] = sp_atan2(-sp_dot3(f->Yc, f->Xp), sp_dot3(f->Xc, f->Xp));
   sp_copy3(f->Xp, f->ax[0]);
   sp_copy3(f->Zc, f->ax[2]);
   real n[3];
   sp_cross3(f->Zc, f->Xp, n);
-  real inv = R(1) / (sp_sqrt(sp_dot3(n, n)) + R(1e-10));
+  real inv = R(1) / (cb + R(1e-10));
   sp_scale3(n, inv, f->ax[1]);
 }
 
@@ -266,7 +267,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     for (int c = l + 1; c < L; ++c)
       if (m->parent[c] == l) { sp_add3(dp, dp_p[c], dp); sp_add3(dth, dp_th[c], dth); }
     sp_add3(x[l].p, dp, x[l].p);
-    sp_qrotvec(x[l].r, dth);
+    sp_qrotvec_raw(x[l].r, dth); /* renormalised at the end of stage (4) */
   }
   /* ---- (4) geometry.contact (sphere-plane) + collisions.resolve_position */
   contact_t con[MBD_MAX_COL];
@@ -310,8 +311,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_axpy3(in[l].inv_mass, Pimp, cd_p[l]);
     sp_cross3(rc, Pimp, mom); iinv_apply(&in[l], mom, t); sp_add3(cd_th[l], t, cd_th[l]);
   }
-  for (int l = 0; l < L; ++l) {
-    if (!has_col[l]) continue;
+  for (int l = 0; l < L; ++l) { /* all links: zero corrections where there is no collider */
     sp_add3(x[l].p, cd_p[l], x[l].p);
     sp_qrotvec(x[l].r, cd_th[l]);
   }

@@ -131,10 +131,25 @@ static inline real sp_atan2(real y, real x) {
   if (x < R(0)) r = R(3.14159265358979323846) - r;
   return y < R(0) ? -r : r;
 }
-/* asin(v) for |v| <= 1 via atan2(v, sqrt(1 - v^2)) */
-static inline real sp_asin(real v) {
+/* asin(v) for |v| <= 1 via atan2(v, sqrt(1 - v^2)); *cos_out = sqrt(1 - v^2) */
+static inline real sp_asin_c(real v, real* cos_out) {
   real c2 = sp_fma(-v, v, R(1));
-  return sp_atan2(v, sp_sqrt(c2 < R(0) ? R(0) : c2));
+  real c = sp_sqrt(c2 < R(0) ? R(0) : c2);
+  *cos_out = c;
+  return sp_atan2(v, c);
+}
+static inline real sp_asin(real v) {
+  real c;
+  return sp_asin_c(v, &c);
+}
+/* q <- q + 0.5*(0,th) (x) q  WITHOUT renormalisation (|q|^2 - 1 = |th|^2/4, renormalised by the next update) */
+static inline void sp_qrotvec_raw(real q[4], const real th[3]) {
+  real h[3] = {R(0.5) * th[0], R(0.5) * th[1], R(0.5) * th[2]};
+  real w = sp_fma(-h[2], q[3], sp_fma(-h[1], q[2], sp_fma(-h[0], q[1], q[0])));
+  real x = sp_fma(-h[2], q[2], sp_fma(h[1], q[3], sp_fma(h[0], q[0], q[1])));
+  real y = sp_fma(h[2], q[1], sp_fma(h[1], q[0], sp_fma(-h[0], q[3], q[2])));
+  real z = sp_fma(h[2], q[0], sp_fma(-h[1], q[1], sp_fma(h[0], q[2], q[3])));
+  q[0] = w; q[1] = x; q[2] = y; q[3] = z;
 }
 
 /* sin & cos, |x| < ~1e4: Cody–Waite reduction by pi/2 with fma, cephes sinf/cosf minimax kernels */

@@ -191,3 +191,60 @@ def test_full_size_properties_humanoidrun(gpu):
     r2, d2 = run_diffusion(args, return_details=True)
     assert np.array_equal(d1["mu_0ts"], d2["mu_0ts"]) and r1 == r2
     assert np.isfinite(d1["mu_0ts"]).all() and np.abs(d1["mu_0ts"]).max() <= 1.0
+
+
+def test_two_shards_on_one_gpu_match_unsharded(gpu):
+    """The N>1 code path on a single GPU: two plans owning candidates [0,N/2) and [N/2,N) plus a manual
+    'all-gather' must give exactly the unsharded Ybar (this is what every rank computes with G GPUs)."""
+    import torch
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.mbd_planner import Args, Plan
+    N, H, Nd, i = 256, 50, 100, 80
+    env = get_env("humanoidrun")
+    args = Args(env_name="humanoidrun", Nsample=N, Hsample=H, Ndiffuse=Nd, temp_sample=0.1,
+                disable_recommended_params=True, not_render=True)
+    st = env.reset(gpu.prng_key(2))
+    ks = gpu.key_array(gpu.prng_split(gpu.prng_key(9), 2)[1])
+    g = np.random.default_rng(1)
+    Ybar = torch.tensor((g.normal(size=H * 17) * 0.2).astype(np.float32), device="cuda")
+    outs = []
+    for shards in ([(0, N)], [(0, N // 2), (N // 2, N // 2)], [(0, 64), (64, 64), (128, 64), (192, 64)]):
+        plans = [Plan(env, args, shard_begin=b, shard_count=c) for b, c in shards]
+        allv = torch.zeros(N, device="cuda")
+        for p, (b, c) in zip(plans, shards):
+            p.set_state0(st)
+            loc = torch.zeros(c, device="cuda")
+            gpu.check(p.lib.mbd_plan_sample_rollout(p.h, i, ks, Ybar.data_ptr(), loc.data_ptr(), None, None))
+            torch.cuda.synchronize()
+            allv[b:b + c] = loc
+        res = []
+        for p in plans:  # every "rank" finishes the step from the same gathered rewards
+            out, rm = torch.zeros(H * 17, device="cuda"), torch.zeros(1, device="cuda")
+            gpu.check(p.lib.mbd_plan_score_update(p.h, i, ks, Ybar.data_ptr(), allv.data_ptr(), None,
+                                                  out.data_ptr(), rm.data_ptr(), None))
+            torch.cuda.synchronize()
+            res.append((out.cpu().numpy(), rm.item()))
+            p.close()
+        assert all(np.array_equal(res[0][0], r[0]) and res[0][1] == r[1] for r in res)
+        outs.append(res[0])
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][0], outs[2][0])
+    assert outs[0][1] == outs[1][1] == outs[2][1]
+
+
+def test_reverse_distributed_world1_equals_plan_run(gpu):
+    """The Python step loop used for multi-GPU runs (world size 1 here) against the C loop mbd_plan_run."""
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.mbd_planner import Args, Plan, reverse_distributed
+    args = Args(env_name="hopper", Nsample=128, Hsample=50, Ndiffuse=15, temp_sample=0.1,
+                disable_recommended_params=True, not_render=True)
+    env = get_env("hopper")
+    st = env.reset(gpu.prng_key(4))
+    key = gpu.prng_key(8)
+    p1 = Plan(env, args)
+    p1.set_state0(st)
+    mu1, rm1, rf1, _ = p1.run(key)
+    p2 = Plan(env, args)
+    p2.set_state0(st)
+    mu2, rm2 = reverse_distributed(p2, key, 0)
+    assert np.array_equal(mu1, mu2.cpu().numpy()) and np.array_equal(rm1, rm2.cpu().numpy())
+    assert p2.eval(mu1[-1]) == rf1
