@@ -82,12 +82,15 @@ __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp,
   q4 acrot = qmul(Cr, jc.ac_rot);
   axes3 A = qaxes(f.aprot), C = qaxes(acrot);
   f.Xp = A.X; f.Xc = C.X; f.Yc = C.Y; f.Zc = C.Z;
-  f.ang0 = atan2_(-dot(C.Z, A.Y), dot(C.Z, A.Z));
-  float cb;  // cos of the middle angle = |Zc x Xp|
-  f.ang1 = asin_c(fclip(dot(C.Z, A.X), -1.0f, 1.0f), &cb);
-  f.ang2 = atan2_(-dot(C.Y, A.X), dot(C.X, A.X));
-  v3 n = cross(C.Z, A.X);
+  // sin b = Zc.Xp; (sin a, cos a) and (sin c, cos c) both have length cos b: one reciprocal for all
+  float sb = fclip(dot(C.Z, A.X), -1.0f, 1.0f);
+  float cb2 = ffma(-sb, sb, 1.0f);
+  float cb = fsqrt(cb2 < 0.0f ? 0.0f : cb2);
   float inv = 1.0f / (cb + 1e-10f);
+  f.ang0 = angle_unit(-dot(C.Z, A.Y) * inv, dot(C.Z, A.Z) * inv);
+  f.ang1 = angle_unit(sb, cb);
+  f.ang2 = angle_unit(-dot(C.Y, A.X) * inv, dot(C.X, A.X) * inv);
+  v3 n = cross(C.Z, A.X);
   f.ax1 = scale(n, inv);
   return f;
 }
@@ -227,15 +230,17 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
   if (!link_ok) { p = mk3(0, 0, 0); r = q4{1, 0, 0, 0}; v = mk3(0, 0, 0); w = mk3(0, 0, 0); }
 
   const float* u_row = P.us + (size_t)b * H * Nu;
-  float u_rot[3], u_sl[3];
-  auto load_actions = [&](int t) {
+  float u_rot[3], u_sl[3];     // actions of the current control step
+  float un_rot[3], un_sl[3];   // actions of the next one, in flight while the substeps run
+  auto load_actions = [&](int t, float (&ur)[3], float (&us)[3]) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      u_rot[k] = act_rot[k] >= 0 ? u_row[(size_t)t * Nu + act_rot[k]] : 0.0f;
-      if constexpr (SLIDES) u_sl[k] = act_sl[k] >= 0 ? u_row[(size_t)t * Nu + act_sl[k]] : 0.0f;
+      ur[k] = u_row[(size_t)t * Nu + (act_rot[k] >= 0 ? act_rot[k] : 0)];
+      if constexpr (SLIDES) us[k] = u_row[(size_t)t * Nu + (act_sl[k] >= 0 ? act_sl[k] : 0)];
+      else us[k] = 0.0f;
     }
   };
-  load_actions(0);
+  load_actions(0, u_rot, u_sl);
   float rew_sum = 0.0f;
 
   for (int t = 0; t < H; ++t) {
@@ -243,8 +248,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
     float tau[3], tau_sl[3];
 #pragma unroll
     for (int k = 0; k < 3; ++k) {
-      tau[k] = fclip(u_rot[k], alo_rot[k], ahi_rot[k]) * gear_rot[k];
-      tau_sl[k] = SLIDES ? fclip(u_sl[k], alo_sl[k], ahi_sl[k]) * gear_sl[k] : 0.0f;
+      tau[k] = fclip(act_rot[k] >= 0 ? u_rot[k] : 0.0f, alo_rot[k], ahi_rot[k]) * gear_rot[k];
+      tau_sl[k] = SLIDES ? fclip(act_sl[k] >= 0 ? u_sl[k] : 0.0f, alo_sl[k], ahi_sl[k]) * gear_sl[k] : 0.0f;
     }
     float ctrl_cost = 0.0f;
     if (rkind == MBD_REW_HALFCHEETAH && l_raw == 0) {
@@ -253,7 +258,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         ctrl_cost = ctrl_cost + ua * ua;
       }
     }
-    if (t + 1 < H) load_actions(t + 1);  // prefetch the next control step's actions
+    // issue the next control step's action loads now (clamped index: no branch) and keep them in flight
+    // across the n_frames substeps; they are consumed at the top of the next iteration
+    load_actions(t + 1 < H ? t + 1 : t, un_rot, un_sl);
+    __builtin_amdgcn_sched_barrier(0);
     // link-frame origin before the step (rewards that look at the incoming state / finite differences)
     const v3 o0 = sub(p, rot(com, r));
     const v3 v0 = sub(v, cross(w, rot(com, r)));
@@ -465,6 +473,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       float* o = P.xpos + (((size_t)b * H + t) * K + track_k) * 3;
       o[0] = o1.x; o[1] = o1.y; o[2] = o1.z;
     }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { u_rot[k] = un_rot[k]; u_sl[k] = un_sl[k]; }
   }  // control steps
   if (l_raw == 0 && b_ok && P.rews) P.rews[b] = rew_sum / (float)H;
   if (P.state_final && link_ok && b_ok) {

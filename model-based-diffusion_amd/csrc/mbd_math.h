@@ -60,9 +60,12 @@ MBD_HD q4 qmul(q4 a, q4 b) {
   o.z = ffma(a.z, b.w, ffma(-a.y, b.x, ffma(a.x, b.y, a.w * b.z)));
   return o;
 }
+// 1/sqrt(1+e) by its 4th-order series for |e| <= 0.05 (error < 1e-7), exact beyond
 MBD_HD q4 qnormalize(q4 q) {
   float n2 = ffma(q.w, q.w, ffma(q.x, q.x, ffma(q.y, q.y, q.z * q.z)));
-  float inv = 1.0f / fsqrt(n2);
+  float e = n2 - 1.0f;
+  float inv = ffma(ffma(ffma(ffma(0.2734375f, e, -0.3125f), e, 0.375f), e, -0.5f), e, 1.0f);
+  if (__builtin_expect(fabs_(e) > 0.05f, 0)) inv = 1.0f / fsqrt(n2);
   return q4{q.w * inv, q.x * inv, q.y * inv, q.z * inv};
 }
 // q + 0.5 (0,th) (x) q, not renormalised
@@ -111,11 +114,23 @@ MBD_HD float atan2_(float y, float x) {
   r = x < 0.0f ? 3.14159265358979323846f - r : r;
   return y < 0.0f ? -r : r;
 }
-MBD_HD float asin_c(float v, float* cos_out) {  // also returns sqrt(1 - v^2)
-  float c2 = ffma(-v, v, 1.0f);
-  float c = fsqrt(c2 < 0.0f ? 0.0f : c2);
-  *cos_out = c;
-  return atan2_(v, c);
+// angle of the near-unit vector (c, s) in (-pi, pi], division-free: asin of min(|s|,|c|) + octant fix-ups
+MBD_HD float angle_unit(float s, float c) {
+  float as = fabs_(s), ac = fabs_(c);
+  bool swap = as > ac;
+  float u = swap ? ac : as;
+  float z = u * u;
+  float p = 0.11199134588241577f;
+  p = ffma(p, z, -0.09445883333683014f);
+  p = ffma(p, z, 0.07875244319438934f);
+  p = ffma(p, z, 0.015578965656459332f);
+  p = ffma(p, z, 0.04668578505516052f);
+  p = ffma(p, z, 0.07486556470394135f);
+  p = ffma(p, z, 0.16666975617408752f);
+  float r = ffma(p * z, u, u);
+  r = swap ? 1.57079632679489661923f - r : r;
+  r = c < 0.0f ? 3.14159265358979323846f - r : r;
+  return s < 0.0f ? -r : r;
 }
 MBD_HD void sincos_(float x, float* s_out, float* c_out) {
   float k = __builtin_rintf(x * 0.63661977236758134308f);

@@ -82,16 +82,20 @@ static void joint_frames(const mbd_model_t* m, int l, const xf_t* P, const xf_t*
   sp_qmul(C->r, acrot, f->acrot);
   sp_qaxes(f->aprot, f->Xp, f->Yp, f->Zp);
   sp_qaxes(f->acrot, f->Xc, f->Yc, f->Zc);
-  /* R_rel = Rx(a) Ry(b) Rz(c), columns = child axes in the parent joint frame */
-  f->ang[0] = sp_atan2(-sp_dot3(f->Zc, f->Yp), sp_dot3(f->Zc, f->Zp));
-  real cb; /* cos of the middle angle = |Zc x Xp| */
-  f->ang[1] = sp_asin_c(sp_clip(sp_dot3(f->Zc, f->Xp), R(-1), R(1)), &cb);
-  f->ang[2] = sp_atan2(-sp_dot3(f->Yc, f->Xp), sp_dot3(f->Xc, f->Xp));
+  /* R_rel = Rx(a) Ry(b) Rz(c), columns = child axes in the parent joint frame.  sin b = Zc.Xp; both
+   * (sin a, cos a) ~ (-Zc.Yp, Zc.Zp) and (sin c, cos c) ~ (-Yc.Xp, Xc.Xp) have length cos b, so one
+   * reciprocal normalises them and the line of nodes Zc x Xp */
+  real sb = sp_clip(sp_dot3(f->Zc, f->Xp), R(-1), R(1));
+  real cb2 = sp_fma(-sb, sb, R(1));
+  real cb = sp_sqrt(cb2 < R(0) ? R(0) : cb2);
+  real inv = R(1) / (cb + R(1e-10));
+  f->ang[0] = sp_angle_unit(-sp_dot3(f->Zc, f->Yp) * inv, sp_dot3(f->Zc, f->Zp) * inv);
+  f->ang[1] = sp_angle_unit(sb, cb);
+  f->ang[2] = sp_angle_unit(-sp_dot3(f->Yc, f->Xp) * inv, sp_dot3(f->Xc, f->Xp) * inv);
   sp_copy3(f->Xp, f->ax[0]);
   sp_copy3(f->Zc, f->ax[2]);
   real n[3];
   sp_cross3(f->Zc, f->Xp, n);
-  real inv = R(1) / (cb + R(1e-10));
   sp_scale3(n, inv, f->ax[1]);
 }
 

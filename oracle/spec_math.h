@@ -82,10 +82,14 @@ static inline void sp_qmul(const real a[4], const real b[4], real o[4]) {
   real z = sp_fma(a[3], b[0], sp_fma(-a[2], b[1], sp_fma(a[1], b[2], a[0] * b[3])));
   o[0] = w; o[1] = x; o[2] = y; o[3] = z;
 }
-/* q <- q / |q| : one sqrt, one reciprocal, four multiplies */
+/* q <- q / |q|.  Quaternions are renormalised after every first-order update, so e = |q|^2 - 1 is
+ * tiny: 1/sqrt(1+e) = 1 - e/2 + 3e^2/8 - 5e^3/16 + 35e^4/128 (error 63/256 e^5 < 1e-7 for |e| <= 0.05,
+ * i.e. up to 0.45 rad of rotation per substep); beyond that the exact sqrt + reciprocal. */
 static inline void sp_qnormalize(real q[4]) {
   real n2 = sp_fma(q[0], q[0], sp_fma(q[1], q[1], sp_fma(q[2], q[2], q[3] * q[3])));
-  real inv = R(1) / sp_sqrt(n2);
+  real e = n2 - R(1);
+  real inv = sp_fma(sp_fma(sp_fma(sp_fma(R(0.2734375), e, R(-0.3125)), e, R(0.375)), e, R(-0.5)), e, R(1));
+  if (sp_abs(e) > R(0.05)) inv = R(1) / sp_sqrt(n2);
   q[0] = q[0] * inv; q[1] = q[1] * inv; q[2] = q[2] * inv; q[3] = q[3] * inv;
 }
 /* q <- normalize(q + 0.5*(0,th) (x) q): first-order update by the rotation vector th */
@@ -131,16 +135,29 @@ static inline real sp_atan2(real y, real x) {
   if (x < R(0)) r = R(3.14159265358979323846) - r;
   return y < R(0) ? -r : r;
 }
-/* asin(v) for |v| <= 1 via atan2(v, sqrt(1 - v^2)); *cos_out = sqrt(1 - v^2) */
-static inline real sp_asin_c(real v, real* cos_out) {
-  real c2 = sp_fma(-v, v, R(1));
-  real c = sp_sqrt(c2 < R(0) ? R(0) : c2);
-  *cos_out = c;
-  return sp_atan2(v, c);
+/* angle of the (near-)unit vector (c, s), in (-pi, pi], WITHOUT a division: asin of the smaller of
+ * |s|, |c| (<= 0.7072) by the odd minimax polynomial u + u^3 P(u^2) (|err| <= 5.3e-8), then octant
+ * fix-ups. */
+static inline real sp_angle_unit(real s, real c) {
+  real as = sp_abs(s), ac = sp_abs(c);
+  int swap = as > ac;
+  real u = swap ? ac : as;
+  real z = u * u;
+  real p = R(0.11199134588241577);
+  p = sp_fma(p, z, R(-0.09445883333683014));
+  p = sp_fma(p, z, R(0.07875244319438934));
+  p = sp_fma(p, z, R(0.015578965656459332));
+  p = sp_fma(p, z, R(0.04668578505516052));
+  p = sp_fma(p, z, R(0.07486556470394135));
+  p = sp_fma(p, z, R(0.16666975617408752));
+  real r = sp_fma(p * z, u, u);
+  if (swap) r = R(1.57079632679489661923) - r;
+  if (c < R(0)) r = R(3.14159265358979323846) - r;
+  return s < R(0) ? -r : r;
 }
-static inline real sp_asin(real v) {
-  real c;
-  return sp_asin_c(v, &c);
+static inline real sp_asin(real v) { /* |v| <= 1 */
+  real c2 = sp_fma(-v, v, R(1));
+  return sp_angle_unit(v, sp_sqrt(c2 < R(0) ? R(0) : c2));
 }
 /* q <- q + 0.5*(0,th) (x) q  WITHOUT renormalisation (|q|^2 - 1 = |th|^2/4, renormalised by the next update) */
 static inline void sp_qrotvec_raw(real q[4], const real th[3]) {
