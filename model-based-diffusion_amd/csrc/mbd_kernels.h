@@ -64,6 +64,7 @@ __device__ __forceinline__ v3 iinv(const Inert<ISO>& in, q4 r, v3 v) {
 
 struct JointFrames {
   v3 ap, ac;
+  v3x2 anchor;  // (ap, ac) packed
   q4 aprot;
   v3 Xp, Xc, Yc, Zc, ax1;
   float ang0, ang1, ang2;
@@ -76,11 +77,15 @@ struct JointConst {
 
 __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp, q4 Pr, v3 Cp, q4 Cr) {
   JointFrames f;
-  f.ap = add(Pp, rot(jc.ap_pos, Pr));
-  f.ac = add(Cp, rot(jc.ac_pos, Cr));
-  f.aprot = qmul(Pr, jc.ap_rot);
-  q4 acrot = qmul(Cr, jc.ac_rot);
-  axes3 A = qaxes(f.aprot), C = qaxes(acrot);
+  // parent side in the low halves, child side in the high halves of packed pairs
+  const q4x2 R2 = pack4(Pr, Cr);
+  const v3x2 anchor = add2(pack3(Pp, Cp), rot2(pack3(jc.ap_pos, jc.ac_pos), R2));
+  const q4x2 arot = qmul2(R2, pack4(jc.ap_rot, jc.ac_rot));
+  const axes3x2 AX = qaxes2(arot);
+  f.ap = lo3(anchor); f.ac = hi3(anchor);
+  f.anchor = anchor;
+  f.aprot = lo4(arot);
+  struct { v3 X, Y, Z; } A{lo3(AX.X), lo3(AX.Y), lo3(AX.Z)}, C{hi3(AX.X), hi3(AX.Y), hi3(AX.Z)};
   f.Xp = A.X; f.Xc = C.X; f.Yc = C.Y; f.Zc = C.Z;
   // sin b = Zc.Xp; (sin a, cos a) and (sin c, cos c) both have length cos b: one reciprocal for all
   float sb = fclip(dot(C.Z, A.X), -1.0f, 1.0f);
@@ -95,16 +100,32 @@ __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp,
   return f;
 }
 
-// one angular positional correction (rotate child by +e, parent by -e): I^-1 e * |e|^2 /
-// (e.I_p^-1 e + e.I_c^-1 e) — one division, no square root
+// (parent, child) pair of inverse-inertia applications: low half with the parent's tensor/orientation,
+// high half with the child's
 template <bool ISO>
-__device__ __forceinline__ void ang_correct(v3 e, const Inert<ISO>& ip, q4 Pr, const Inert<ISO>& ic, q4 Cr,
-                                            float sc, v3& dth_p, v3& dth_c) {
-  v3 inp = iinv<ISO>(ip, Pr, e), inc = iinv<ISO>(ic, Cr, e);
-  float den = dot(e, inp) + dot(e, inc);
+__device__ __forceinline__ v3x2 iinv2(const Inert<ISO>& ip, const Inert<ISO>& ic, q4x2 R2, v3x2 v) {
+  if constexpr (ISO) {
+    return scale2(v, mk2(ip.ib[0], ic.ib[0]));
+  } else {
+    q4x2 Rc{R2.w, -R2.x, -R2.y, -R2.z};
+    v3x2 l = rot2(v, Rc), m;
+    m.x = fma2(mk2(ip.ib[4], ic.ib[4]), l.z, fma2(mk2(ip.ib[3], ic.ib[3]), l.y, mk2(ip.ib[0], ic.ib[0]) * l.x));
+    m.y = fma2(mk2(ip.ib[5], ic.ib[5]), l.z, fma2(mk2(ip.ib[1], ic.ib[1]), l.y, mk2(ip.ib[3], ic.ib[3]) * l.x));
+    m.z = fma2(mk2(ip.ib[2], ic.ib[2]), l.z, fma2(mk2(ip.ib[5], ic.ib[5]), l.y, mk2(ip.ib[4], ic.ib[4]) * l.x));
+    return rot2(m, R2);
+  }
+}
+// one angular positional correction (rotate child by +e, parent by -e): I^-1 e * |e|^2 /
+// (e.I_p^-1 e + e.I_c^-1 e) — one division, no square root. dth2 = (dth_p, dth_c) packed.
+template <bool ISO>
+__device__ __forceinline__ void ang_correct(v3 e, const Inert<ISO>& ip, const Inert<ISO>& ic, q4x2 R2, float sc,
+                                            v3x2& dth2) {
+  v3x2 e2 = bcast3(e);
+  v3x2 in2 = iinv2<ISO>(ip, ic, R2, e2);  // (I_p^-1 e, I_c^-1 e)
+  f2 d2 = dot2(e2, in2);
+  float den = d2.x + d2.y;
   float g = (dot(e, e) / (den + 1e-20f)) * sc;
-  dth_c = axpy(g, inc, dth_c);
-  dth_p = axpy(-g, inp, dth_p);
+  dth2 = axpy2(mk2(-g, g), in2, dth2);
 }
 // contact normal = +z of the floor plane
 __device__ __forceinline__ v3 crossz(v3 a) { return v3{a.y, -a.x, 0.0f}; }
@@ -274,9 +295,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       v3 fc_v, fc_w, fp_v, fp_w;
       {
         JointFrames f = joint_frames(jc, Pp, Pr, p, r);
-        v3 rc = sub(f.ac, p), rp = sub(f.ap, Pp);
-        v3 vc = add(v, cross(w, rc)), vp = add(Pv, cross(Pw, rp));
-        v3 rel_v = sub(vc, vp), rel_w = sub(w, Pw);
+        const q4x2 R2 = pack4(Pr, r);
+        const v3x2 arm = sub2(f.anchor, pack3(Pp, p));                 // (rp, rc)
+        const v3x2 va = add2(pack3(Pv, v), cross2(pack3(Pw, w), arm));  // anchor velocities (vp, vc)
+        v3 rel_v = sub(hi3(va), lo3(va)), rel_w = sub(w, Pw);
         v3 T = mk3(0, 0, 0), F = mk3(0, 0, 0);
         auto torque = [&](int k, v3 ax, float ang) {
           float qdk = dot(rel_w, ax);
@@ -298,10 +320,13 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         }
         T = axpy(-ang_damp, rel_w, T);
         F = axpy(-vel_damp, rel_v, F);
-        fc_v = scale(F, ic.inv_mass);
-        fc_w = iinv<ISO>(ic, r, add(T, cross(rc, F)));
-        fp_v = scale(F, -ip.inv_mass);
-        fp_w = scale(iinv<ISO>(ip, Pr, add(T, cross(rp, F))), -1.0f);
+        // child: +F at its anchor, +T; parent: -F at its anchor, -T
+        const v3x2 F2 = bcast3(F);
+        const v3x2 lin = scale2(F2, mk2(-ip.inv_mass, ic.inv_mass));       // (fp_v, fc_v)
+        const v3x2 tot = add2(bcast3(T), cross2(arm, F2));
+        const v3x2 ang = scale2(iinv2<ISO>(ip, ic, R2, tot), mk2(-1.0f, 1.0f));  // (fp_w, fc_w)
+        fc_v = hi3(lin); fp_v = lo3(lin);
+        fc_w = hi3(ang); fp_w = lo3(ang);
       }
       // ---- (2) integrator.integrate_xdd -------------------------------------------------------------
       v3 av = fc_v, aw = fc_w;
@@ -338,31 +363,33 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
             d = axpy(cf, s, d);
           }
         }
-        v3 rc = sub(f.ac, p), rp = sub(f.ap, Pp);
+        const q4x2 R2 = pack4(Pr, r);
+        const v3x2 arm = sub2(f.anchor, pack3(Pp, p));  // (rp, rc)
         float c2 = dot(d, d);
-        v3 cp = cross(rp, d), cc = cross(rc, d);
-        v3 icp = iinv<ISO>(ip, Pr, cp), icc = iinv<ISO>(ic, r, cc);
-        float den = ffma(invm_sum, c2, dot(cp, icp) + dot(cc, icc));
+        const v3x2 d2 = bcast3(d);
+        const v3x2 cr = cross2(arm, d2);                       // (rp x d, rc x d)
+        const f2 wq = dot2(cr, iinv2<ISO>(ip, ic, R2, cr));
+        float den = ffma(invm_sum, c2, wq.x + wq.y);
         float g = (c2 / (den + 1e-20f)) * js_pos;
-        v3 Pimp = scale(d, g);
-        dc_p = scale(Pimp, ic.inv_mass);
-        dc_th = iinv<ISO>(ic, r, cross(rc, Pimp));
-        dp_p = scale(Pimp, -ip.inv_mass);
-        dp_th = scale(iinv<ISO>(ip, Pr, cross(rp, Pimp)), -1.0f);
+        const v3x2 P2 = bcast3(scale(d, g));
+        const v3x2 lin = scale2(P2, mk2(-ip.inv_mass, ic.inv_mass));  // (dp_p, dc_p)
+        v3x2 dth2 = scale2(iinv2<ISO>(ip, ic, R2, cross2(arm, P2)), mk2(-1.0f, 1.0f));  // (dp_th, dc_th)
         // angular alignment by joint type (1 hinge: Xc || Xp; 2 hinges: Yc _|_ Xp; 3: free)
         v3 A = sel3(nr == 1, f.Xc, f.Xp);
         v3 Bv = sel3(nr == 1, f.Xp, f.Yc);
         float sc = nr_eff == 1 ? 1.0f : (nr_eff == 2 ? dot(f.Xp, f.Yc) : 0.0f);
         v3 e = scale(cross(A, Bv), sc);
-        ang_correct<ISO>(e, ip, Pr, ic, r, js_ang, dp_th, dc_th);
+        ang_correct<ISO>(e, ip, ic, R2, js_ang, dth2);
         auto limit = [&](int k, v3 ax, float a) {
           float viol = a < lim_lo[k] ? a - lim_lo[k] : (a > lim_hi[k] ? a - lim_hi[k] : 0.0f);
           viol = k < nr_eff ? viol : 0.0f;
-          ang_correct<ISO>(scale(ax, -viol), ip, Pr, ic, r, js_ang, dp_th, dc_th);
+          ang_correct<ISO>(scale(ax, -viol), ip, ic, R2, js_ang, dth2);
         };
         limit(0, f.Xp, f.ang0);
         limit(1, f.ax1, f.ang1);
         limit(2, f.Zc, f.ang2);
+        dc_p = hi3(lin); dp_p = lo3(lin);
+        dc_th = hi3(dth2); dp_th = lo3(dth2);
       }
       {
         v3 dp = dc_p, dth = dc_th;

@@ -95,6 +95,62 @@ MBD_HD axes3 qaxes(q4 q) {
   return a;
 }
 
+// ---- pairs: the same primitives on two operands at once (v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32:
+// one VALU issue slot for both).  Component-wise identical roundings to the scalar versions.
+typedef float f2 __attribute__((ext_vector_type(2)));
+struct v3x2 {
+  f2 x, y, z;
+};
+struct q4x2 {
+  f2 w, x, y, z;
+};
+__device__ __forceinline__ f2 fma2(f2 a, f2 b, f2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f2 mk2(float a, float b) { return f2{a, b}; }
+__device__ __forceinline__ v3x2 pack3(v3 a, v3 b) { return v3x2{mk2(a.x, b.x), mk2(a.y, b.y), mk2(a.z, b.z)}; }
+__device__ __forceinline__ q4x2 pack4(q4 a, q4 b) { return q4x2{mk2(a.w, b.w), mk2(a.x, b.x), mk2(a.y, b.y), mk2(a.z, b.z)}; }
+__device__ __forceinline__ v3 lo3(v3x2 a) { return v3{a.x.x, a.y.x, a.z.x}; }
+__device__ __forceinline__ v3 hi3(v3x2 a) { return v3{a.x.y, a.y.y, a.z.y}; }
+__device__ __forceinline__ q4 lo4(q4x2 a) { return q4{a.w.x, a.x.x, a.y.x, a.z.x}; }
+__device__ __forceinline__ v3x2 cross2(v3x2 a, v3x2 b) {
+  return v3x2{fma2(a.y, b.z, -(a.z * b.y)), fma2(a.z, b.x, -(a.x * b.z)), fma2(a.x, b.y, -(a.y * b.x))};
+}
+__device__ __forceinline__ v3x2 add2(v3x2 a, v3x2 b) { return v3x2{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ v3x2 rot2(v3x2 v, q4x2 q) {
+  v3x2 u{q.x, q.y, q.z};
+  v3x2 t = cross2(u, v);
+  t = v3x2{t.x + t.x, t.y + t.y, t.z + t.z};
+  v3x2 c = cross2(u, t);
+  return v3x2{fma2(q.w, t.x, v.x) + c.x, fma2(q.w, t.y, v.y) + c.y, fma2(q.w, t.z, v.z) + c.z};
+}
+__device__ __forceinline__ q4x2 qmul2(q4x2 a, q4x2 b) {
+  q4x2 o;
+  o.w = fma2(-a.z, b.z, fma2(-a.y, b.y, fma2(-a.x, b.x, a.w * b.w)));
+  o.x = fma2(-a.z, b.y, fma2(a.y, b.z, fma2(a.x, b.w, a.w * b.x)));
+  o.y = fma2(a.z, b.x, fma2(a.y, b.w, fma2(-a.x, b.z, a.w * b.y)));
+  o.z = fma2(a.z, b.w, fma2(-a.y, b.x, fma2(a.x, b.y, a.w * b.z)));
+  return o;
+}
+__device__ __forceinline__ v3x2 sub2(v3x2 a, v3x2 b) { return v3x2{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ v3x2 bcast3(v3 a) { return v3x2{mk2(a.x, a.x), mk2(a.y, a.y), mk2(a.z, a.z)}; }
+__device__ __forceinline__ v3x2 scale2(v3x2 a, f2 s) { return v3x2{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ f2 dot2(v3x2 a, v3x2 b) { return fma2(a.x, b.x, fma2(a.y, b.y, a.z * b.z)); }
+__device__ __forceinline__ v3x2 axpy2(f2 s, v3x2 a, v3x2 o) { return v3x2{fma2(s, a.x, o.x), fma2(s, a.y, o.y), fma2(s, a.z, o.z)}; }
+struct axes3x2 {
+  v3x2 X, Y, Z;
+};
+__device__ __forceinline__ axes3x2 qaxes2(q4x2 q) {
+  f2 x2 = q.x + q.x, y2 = q.y + q.y, z2 = q.z + q.z;
+  f2 xx = q.x * x2, yy = q.y * y2, zz = q.z * z2;
+  f2 xy = q.x * y2, xz = q.x * z2, yz = q.y * z2;
+  f2 wx = q.w * x2, wy = q.w * y2, wz = q.w * z2;
+  const f2 one = mk2(1.0f, 1.0f);
+  axes3x2 a;
+  a.X = v3x2{one - (yy + zz), xy + wz, xz - wy};
+  a.Y = v3x2{xy - wz, one - (xx + zz), yz + wx};
+  a.Z = v3x2{xz + wy, yz - wx, one - (xx + yy)};
+  return a;
+}
+
 // atan2 with a = min/max in [0,1], atan(a) = a P(a^2) (A&S 4.4.49), octant fix-ups; branch-free
 MBD_HD float atan2_(float y, float x) {
   float ax = fabs_(x), ay = fabs_(y);

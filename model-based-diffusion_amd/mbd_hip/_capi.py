@@ -53,7 +53,7 @@ def load() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    path = os.path.abspath(os.environ.get("MBD_HIP_LIB", LIB_PATH))  # override: kernel A/B builds only
+    path = os.path.abspath(os.environ.get("MBD_HIP_LIB") or LIB_PATH)  # override: kernel A/B builds only
     if not os.path.exists(path):
         raise MbdError(MBD_ERR_STATE, f"{path} is missing: run `python __graft_entry__.py` (build()) first; "
                                       "mbd_hip has no CPU fallback")
