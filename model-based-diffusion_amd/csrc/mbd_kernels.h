@@ -92,9 +92,11 @@ __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp,
   float cb2 = ffma(-sb, sb, 1.0f);
   float cb = fsqrt(cb2 < 0.0f ? 0.0f : cb2);
   float inv = 1.0f / (cb + 1e-10f);
-  f.ang0 = angle_unit(-dot(C.Z, A.Y) * inv, dot(C.Z, A.Z) * inv);
+  const f2 a02 = angle_unit2(mk2(-dot(C.Z, A.Y) * inv, -dot(C.Y, A.X) * inv),
+                             mk2(dot(C.Z, A.Z) * inv, dot(C.X, A.X) * inv));
+  f.ang0 = a02.x;
   f.ang1 = angle_unit(sb, cb);
-  f.ang2 = angle_unit(-dot(C.Y, A.X) * inv, dot(C.X, A.X) * inv);
+  f.ang2 = a02.y;
   v3 n = cross(C.Z, A.X);
   f.ax1 = scale(n, inv);
   return f;
@@ -329,7 +331,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         fc_w = hi3(ang); fp_w = lo3(ang);
       }
       // ---- (2) integrator.integrate_xdd -------------------------------------------------------------
-      v3 av = fc_v, aw = fc_w;
+      v3x2 acc = pack3(fc_v, fc_w);  // (linear, angular) acceleration, packed
 #pragma unroll
       for (int c = 0; c < MAXCH; ++c) {
         v3 cv = shfl3(fp_v, child_src[c]), cw = shfl3(fp_w, child_src[c]);
@@ -337,9 +339,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           cv = sel3(child_lane[c] >= 0, cv, mk3(0, 0, 0));
           cw = sel3(child_lane[c] >= 0, cw, mk3(0, 0, 0));
         }
-        av = add(av, cv);
-        aw = add(aw, cw);
+        acc = add2(acc, pack3(cv, cw));
       }
+      const v3 av = lo3(acc), aw = hi3(acc);
       v = mk3(ffma(av.x + grav.x, dt, vel_fac * v.x), ffma(av.y + grav.y, dt, vel_fac * v.y),
               ffma(av.z + grav.z, dt, vel_fac * v.z));
       w = mk3(ffma(aw.x, dt, ang_fac * w.x), ffma(aw.y, dt, ang_fac * w.y), ffma(aw.z, dt, ang_fac * w.z));
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         dc_th = hi3(dth2); dp_th = lo3(dth2);
       }
       {
-        v3 dp = dc_p, dth = dc_th;
+        v3x2 acc = pack3(dc_p, dc_th);  // (translation, rotation vector), packed
 #pragma unroll
         for (int c = 0; c < MAXCH; ++c) {
           v3 cp = shfl3(dp_p, child_src[c]), cth = shfl3(dp_th, child_src[c]);
@@ -400,11 +402,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
             cp = sel3(child_lane[c] >= 0, cp, mk3(0, 0, 0));
             cth = sel3(child_lane[c] >= 0, cth, mk3(0, 0, 0));
           }
-          dp = add(dp, cp);
-          dth = add(dth, cth);
+          acc = add2(acc, pack3(cp, cth));
         }
-        p = add(p, dp);
-        r = qrotvec_raw(r, dth);  // renormalised at the end of stage (4)
+        p = add(p, lo3(acc));
+        r = qrotvec_raw(r, hi3(acc));  // renormalised at the end of stage (4)
       }
       // ---- (4) sphere-plane contacts + collisions.resolve_position ---------------------------------
       v3 con_pos[MAXCOL];

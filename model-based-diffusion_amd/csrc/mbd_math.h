@@ -188,6 +188,27 @@ MBD_HD float angle_unit(float s, float c) {
   r = c < 0.0f ? 3.14159265358979323846f - r : r;
   return s < 0.0f ? -r : r;
 }
+// two angle_unit() evaluations at once (the polynomial runs on packed pairs)
+__device__ __forceinline__ f2 angle_unit2(f2 s, f2 c) {
+  f2 as = __builtin_elementwise_abs(s), ac = __builtin_elementwise_abs(c);
+  bool sw0 = as.x > ac.x, sw1 = as.y > ac.y;
+  f2 u = mk2(sw0 ? ac.x : as.x, sw1 ? ac.y : as.y);
+  f2 z = u * u;
+  f2 p = mk2(0.11199134588241577f, 0.11199134588241577f);
+  p = fma2(p, z, mk2(-0.09445883333683014f, -0.09445883333683014f));
+  p = fma2(p, z, mk2(0.07875244319438934f, 0.07875244319438934f));
+  p = fma2(p, z, mk2(0.015578965656459332f, 0.015578965656459332f));
+  p = fma2(p, z, mk2(0.04668578505516052f, 0.04668578505516052f));
+  p = fma2(p, z, mk2(0.07486556470394135f, 0.07486556470394135f));
+  p = fma2(p, z, mk2(0.16666975617408752f, 0.16666975617408752f));
+  f2 r = fma2(p * z, u, u);
+  float r0 = r.x, r1 = r.y;
+  r0 = sw0 ? 1.57079632679489661923f - r0 : r0;
+  r1 = sw1 ? 1.57079632679489661923f - r1 : r1;
+  r0 = c.x < 0.0f ? 3.14159265358979323846f - r0 : r0;
+  r1 = c.y < 0.0f ? 3.14159265358979323846f - r1 : r1;
+  return mk2(s.x < 0.0f ? -r0 : r0, s.y < 0.0f ? -r1 : r1);
+}
 MBD_HD void sincos_(float x, float* s_out, float* c_out) {
   float k = __builtin_rintf(x * 0.63661977236758134308f);
   float r = ffma(-k, 1.5703125f, x);
