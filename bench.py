@@ -51,6 +51,24 @@ def pmc_traffic():
     return None, None
 
 
+def valu_view(kern_ms, n_waves, substeps):
+    """FP32 VALU view of the same kernel (the limit that actually binds): static flops per lane per
+    substep from tools/count_flops.py (profiles/rNN_static_flops.json) x lanes x substeps / duration,
+    against the 157.3 TFLOP/s vector-FP32 peak of MI355X_MICROARCH.md."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_static_flops.json")))
+    if not files or kern_ms <= 0:
+        return None
+    with open(files[-1]) as f:
+        d = json.load(f)
+    flops = d["fp32_flops_per_lane_substep"] * 64.0 * n_waves * substeps
+    tf = flops / (kern_ms * 1e-3) / 1e12
+    return {"bound": "fp32-valu-issue", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
+            "flops_per_launch": flops, "valu_instr_per_wave_substep": d["valu_per_substep"],
+            "waves": n_waves, "simds_occupied_frac": min(1.0, n_waves / 1024.0),
+            "source": os.path.basename(files[-1])}
+
+
 def cpu_baseline(seconds_budget=12.0):
     """The oracle (a port, NOT the JAX reference — jax/brax are absent) timed on the host cores on a
     bounded sample of the same workload: consecutive reverse-diffusion steps at N=1024, H=50."""
@@ -103,11 +121,18 @@ def main():
     if rank == 0:
         __graft_entry__.build()
     distributed = world > 1
+    backend = os.environ.get("MBD_DIST_BACKEND", "nccl")  # "gloo": 2-rank dry runs on a single-GPU box
+    n_dev = torch.cuda.device_count()
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            assert n_dev >= world, f"{world} ranks need {world} GPUs, found {n_dev}"
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            local_rank = local_rank % max(n_dev, 1)
+            dist.init_process_group(backend)
         dist.barrier()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch through torch.distributed.run"
 
@@ -145,8 +170,13 @@ def main():
         state["rng"], ks = keys[0], _capi.key_array(keys[1])
         i = state["i"]
         _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Ybar.data_ptr(), local.data_ptr(), None, stream))
-        if distributed:
-            dist.all_gather_into_tensor(allv, local)
+        if distributed and backend == "nccl":
+            dist.all_gather_into_tensor(allv, local)  # the ONE collective of a diffusion step (RCCL/xGMI)
+            src = allv
+        elif distributed:  # gloo dry run: stage through the host
+            host = torch.empty(N_total, dtype=torch.float32)
+            dist.all_gather_into_tensor(host, local.cpu())
+            allv.copy_(host)
             src = allv
         else:
             src = local
@@ -172,7 +202,7 @@ def main():
     plan.enable_timing(False)
     kern_ms, kern_n = plan.kernel_time()
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -211,6 +241,7 @@ def main():
                          "kernel_launches": kern_n, "algorithmic_bytes_per_launch": balg,
                          "note": "state stays in VGPRs for all H*n_frames substeps: the kernel is bound by "
                                  "dependent FP32 VALU issue, not HBM (DESIGN.md §Roofline)"},
+            "valu": valu_view(kern_ms, N_PER_GPU // 4, H * 7),
             "final_reward": final,
         }
         if not args.no_cpu_baseline and world == 1:

@@ -5,5 +5,6 @@ Mirrors the reference package layout for the path (``mbd.envs.get_env``, ``mbd.u
 """
 from . import _capi, envs, model, utils  # noqa: F401
 from . import planners  # noqa: F401
+from . import scripts  # noqa: F401
 
 __all__ = ["envs", "utils", "planners", "model", "_capi"]

@@ -1,0 +1,119 @@
+"""Drop-in for mbd/scripts/run_mbd.py (:17-64): the 8-seed sweep and the 8-temperature sweep.
+
+The reference runs the plans one after another and times each run end to end (`time()` around
+`run_diffusion`, :21,34).  Here the independent plans are ENQUEUED CONCURRENTLY: one `mbd_plan` and one
+HIP stream per plan, the reverse loops stepped round-robin from the host, so that at N=1024 (256
+wavefronts per rollout launch — a quarter of the chip's SIMDs) eight plans overlap on the GPU instead of
+queueing.  Results are bit-identical to running the plans sequentially (tests/test_gpu_parity.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import time
+from dataclasses import dataclass, replace
+
+import numpy as np
+
+from .. import _capi
+from ..envs import get_env
+from ..envs.base import prng_impl
+from ..planners import mbd_planner
+from ..planners.mbd_planner import Plan, apply_recommended
+
+
+@dataclass
+class Args:
+    algo: str = "mbd"  # only "mbd" is on the hot path ("path_integral" is SURVEY §8(f) N2)
+    update_method: str = "mppi"
+    mode: str = "seed"  # "seed" | "temp"
+    env_name: str = "ant"
+
+
+def run_concurrent(plan_args, device: int = 0):
+    """Run several independent MBD plans (a list of mbd_planner.Args) concurrently on one GPU.
+    Returns (rew_final list, mu_0ts list, wall seconds of the whole batch)."""
+    import torch
+    dev = torch.device("cuda", device)
+    impl = prng_impl()
+    jobs = []
+    for a in plan_args:
+        a = replace(a)
+        rng = _capi.prng_key(a.seed)  # mbd_planner.py:40
+        apply_recommended(a)
+        env = get_env(a.env_name, device=device)
+        rng, rng_reset = _capi.prng_split(rng, 2, impl)  # :79
+        state_init = env.reset(rng_reset)
+        rng_exp, _ = _capi.prng_split(rng, 2, impl)  # :150
+        plan = Plan(env, a)
+        plan.set_state0(state_init)
+        HNu = a.Hsample * env.action_size
+        jobs.append(dict(args=a, env=env, plan=plan, stream=torch.cuda.Stream(dev),
+                         key=(C.c_uint32 * 2)(int(rng_exp[0]), int(rng_exp[1])),
+                         Ybar=torch.zeros(HNu, dtype=torch.float32, device=dev),
+                         rew=torch.zeros(1, dtype=torch.float32, device=dev),
+                         mu=torch.zeros((a.Ndiffuse - 1, HNu), dtype=torch.float32, device=dev)))
+    torch.cuda.synchronize(dev)
+    t0 = time.time()
+    nd_max = max(j["args"].Ndiffuse for j in jobs)
+    for step in range(nd_max - 1):  # round-robin: one diffusion step of every plan per pass
+        for j in jobs:
+            a = j["args"]
+            i = a.Ndiffuse - 1 - step
+            if i < 1:
+                continue
+            s = j["stream"]
+            _capi.check(j["plan"].lib.mbd_plan_reverse_once(j["plan"].h, i, j["key"], j["Ybar"].data_ptr(),
+                                                            j["rew"].data_ptr(), s.cuda_stream))
+            with torch.cuda.stream(s):
+                j["mu"][step].copy_(j["Ybar"], non_blocking=True)
+    torch.cuda.synchronize(dev)
+    secs = time.time() - t0
+    rews, mus = [], []
+    for j in jobs:
+        a = j["args"]
+        mu = j["mu"].cpu().numpy().reshape(a.Ndiffuse - 1, a.Hsample, -1)
+        rews.append(j["plan"].eval(mu[-1]))  # mbd_planner.py:179-180
+        mus.append(mu)
+        j["plan"].close()
+    return rews, mus, secs
+
+
+def run_multiple_seed(args: Args, device: int = 0, **plan_kw):
+    """run_mbd.py:17-39: seeds 0..7, mean +- std of the final reward and the time."""
+    if args.algo != "mbd":
+        raise NotImplementedError("only algo='mbd' is implemented on the MI355X hot path")
+    plans = [mbd_planner.Args(seed=seed, env_name=args.env_name, not_render=True, **plan_kw) for seed in range(8)]
+    rews, _, secs = run_concurrent(plans, device)
+    rews = np.array(rews)
+    print(f"rew: {rews.mean():.2f} \\pm {rews.std():.2f}")
+    print(f"time: {secs / len(plans):.2f} per plan ({secs:.2f} s for the concurrent batch of {len(plans)})")
+    return rews, secs
+
+
+def run_multiple_temp(args: Args, device: int = 0, **plan_kw):
+    """run_mbd.py:42-64: temperature sweep at seed 0 with recommended params disabled."""
+    if args.algo != "mbd":
+        raise NotImplementedError("only algo='mbd' is implemented on the MI355X hot path")
+    temps = np.array([0.01, 0.03, 0.06, 0.1, 0.2, 0.4, 0.6, 0.8])
+    plans = [mbd_planner.Args(seed=0, env_name=args.env_name, temp_sample=float(t), not_render=True,
+                              disable_recommended_params=True, **plan_kw) for t in temps]
+    rews, _, secs = run_concurrent(plans, device)
+    rews = np.array(rews)
+    best_temp = temps[np.argmax(rews)]
+    print(f"rews: {rews}")
+    print(f"best_temp: {best_temp:.2f}")
+    return rews, best_temp
+
+
+if __name__ == "__main__":
+    import argparse
+    p = argparse.ArgumentParser()
+    for f in Args.__dataclass_fields__.values():
+        p.add_argument(f"--{f.name}", type=str, default=f.default)
+    a = Args(**vars(p.parse_args()))
+    if a.mode == "seed":
+        run_multiple_seed(a)
+    elif a.mode == "temp":
+        run_multiple_temp(a)
+    else:
+        raise NotImplementedError

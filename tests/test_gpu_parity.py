@@ -248,3 +248,18 @@ def test_reverse_distributed_world1_equals_plan_run(gpu):
     mu2, rm2 = reverse_distributed(p2, key, 0)
     assert np.array_equal(mu1, mu2.cpu().numpy()) and np.array_equal(rm1, rm2.cpu().numpy())
     assert p2.eval(mu1[-1]) == rf1
+
+
+def test_concurrent_seed_sweep_equals_sequential_runs(gpu):
+    """eight plans enqueued concurrently (one stream each) give exactly the results of
+    eight sequential run_diffusion calls (the reference's scripts/run_mbd.py protocol)."""
+    from mbd_hip.planners.mbd_planner import Args, run_diffusion
+    from mbd_hip.scripts.run_mbd import run_concurrent
+    plans = [Args(seed=s, env_name="humanoidrun", Nsample=256, Hsample=50, Ndiffuse=12, temp_sample=0.1,
+                  disable_recommended_params=True, not_render=True) for s in range(4)]
+    plans.append(Args(seed=1, env_name="hopper", Nsample=128, Hsample=50, Ndiffuse=9, temp_sample=0.1,
+                      disable_recommended_params=True, not_render=True))
+    rews, mus, _ = run_concurrent(plans)
+    for a, r, mu in zip(plans, rews, mus):
+        r_seq, det = run_diffusion(a, return_details=True)
+        assert np.array_equal(mu, det["mu_0ts"]) and np.float32(r) == np.float32(r_seq)
