@@ -195,7 +195,12 @@ typedef struct mbd_plan_config {
   int32_t shard_begin; /* this process owns candidates [shard_begin, shard_begin + shard_count)     */
   int32_t shard_count; /* = Nsample on one GPU                                                      */
   int32_t literal_score; /* 1: evaluate score/Yim1/Ybar_im1 literally (:130-133); 0: use identity   */
-  int32_t reserved[5];
+  int32_t update_method; /* 0 = MBD (mbd_planner.py); path-integral baselines of
+                            mbd/planners/path_integral.py:33-52 on the same rollout kernel:
+                            1 = mppi (softmax_update), 2 = cma-es, 3 = cem. For these Ndiffuse plays
+                            Nrefine (:28), sigma is a carried scalar starting at 1.0 (:131), the
+                            standardisation has no zero-std guard (:123) and demos are not used.      */
+  int32_t reserved[4];
 } mbd_plan_config;
 
 int mbd_plan_create(mbd_env* env, const mbd_plan_config* cfg, mbd_plan** out);
@@ -220,6 +225,10 @@ int mbd_plan_sample_rollout(mbd_plan* plan, int i, const uint32_t key_sample[2],
 int mbd_plan_score_update(mbd_plan* plan, int i, const uint32_t key_sample[2], const float* d_Ybar_i,
                           const float* d_rews_all, const float* d_logpd_all, float* d_Ybar_im1,
                           float* d_rew_mean, void* stream);
+/* path-integral plans: the carried sampling sigma (path_integral.py:113,131). set before the first
+ * step (mbd_plan_run does it itself); synchronous. */
+int mbd_plan_set_sigma(mbd_plan* plan, float sigma);
+int mbd_plan_get_sigma(mbd_plan* plan, float* sigma_out);
 /* single-GPU convenience = reverse_once (mbd_planner.py:97-135): phase 1 + phase 2 on `stream`;
  * key_inout is advanced exactly as `rng, Y0s_rng = split(rng)` (:103). async; d_Ybar updated in
  * place; d_rew_mean [1]. */

@@ -86,6 +86,8 @@ struct mbd_plan {
   float *d_state0 = nullptr, *d_Y0s = nullptr, *d_rewss = nullptr, *d_rews = nullptr, *d_lp = nullptr;
   float *d_xpos = nullptr, *d_weights = nullptr, *d_Ybar = nullptr, *d_mu = nullptr, *d_rewmeans = nullptr;
   float *d_scratch = nullptr;
+  float *d_sigma = nullptr, *d_spread = nullptr;  // path-integral plans
+  int* d_idx = nullptr;
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
@@ -420,6 +422,8 @@ extern "C" int mbd_plan_create(mbd_env* env, const mbd_plan_config* cfg, mbd_pla
   if (cfg->Nsample < 1 || cfg->Hsample < 1 || cfg->Ndiffuse < 2) return fail(MBD_ERR_INVALID, "Nsample/Hsample/Ndiffuse");
   if (cfg->shard_begin < 0 || cfg->shard_count < 1 || cfg->shard_begin + cfg->shard_count > cfg->Nsample)
     return fail(MBD_ERR_INVALID, "shard [%d,+%d) outside N=%d", cfg->shard_begin, cfg->shard_count, cfg->Nsample);
+  if (cfg->update_method < 0 || cfg->update_method > 3) return fail(MBD_ERR_INVALID, "update_method=%d", cfg->update_method);
+  if (cfg->update_method > 0 && cfg->enable_demo) return fail(MBD_ERR_INVALID, "path-integral plans do not use demos");
   if (cfg->enable_demo) {
     if (!env->has_xref) return fail(MBD_ERR_INVALID, "enable_demo needs an env created with xref");
     if (cfg->Hsample != 50) return fail(MBD_ERR_INVALID, "demos require Hsample == 50 (xref has 50 rows)");
@@ -445,6 +449,13 @@ extern "C" int mbd_plan_create(mbd_env* env, const mbd_plan_config* cfg, mbd_pla
   HIP_TRY(hipMalloc(&p->d_mu, sizeof(float) * (size_t)(Nd - 1) * p->HNu));
   HIP_TRY(hipMalloc(&p->d_rewmeans, sizeof(float) * (size_t)Nd));
   HIP_TRY(hipMalloc(&p->d_scratch, sizeof(float) * (size_t)(H + 8)));
+  if (cfg->update_method > 0) {
+    HIP_TRY(hipMalloc(&p->d_sigma, sizeof(float)));
+    HIP_TRY(hipMalloc(&p->d_spread, sizeof(float) * (size_t)p->HNu));
+    HIP_TRY(hipMalloc(&p->d_idx, sizeof(int) * 16));
+    const float one = 1.0f;  // path_integral.py:131
+    HIP_TRY(hipMemcpy(p->d_sigma, &one, sizeof(float), hipMemcpyHostToDevice));
+  }
   *out = p;
   return MBD_OK;
 }
@@ -456,6 +467,7 @@ extern "C" int mbd_plan_destroy(mbd_plan* p) {
   (void)hipFree(p->d_state0); (void)hipFree(p->d_Y0s); (void)hipFree(p->d_rewss); (void)hipFree(p->d_rews);
   (void)hipFree(p->d_lp); (void)hipFree(p->d_xpos); (void)hipFree(p->d_weights); (void)hipFree(p->d_Ybar);
   (void)hipFree(p->d_mu); (void)hipFree(p->d_rewmeans); (void)hipFree(p->d_scratch);
+  (void)hipFree(p->d_sigma); (void)hipFree(p->d_spread); (void)hipFree(p->d_idx);
   if (p->stream) (void)hipStreamDestroy(p->stream);
   delete p;
   return MBD_OK;
@@ -493,7 +505,8 @@ extern "C" int mbd_plan_sample_rollout(mbd_plan* p, int i, const uint32_t key_sa
     const uint64_t size = (uint64_t)N * HNu;
     const uint64_t threads = c.prng_impl == MBD_PRNG_PARTITIONABLE ? size : (size + 1) / 2;
     hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, key_sample[0],
-                       key_sample[1], c.prng_impl, N, HNu, p->sigmas[i], d_Ybar_i, p->d_Y0s);
+                       key_sample[1], c.prng_impl, N, HNu, p->sigmas[i],
+                       c.update_method > 0 ? (const float*)p->d_sigma : (const float*)nullptr, d_Ybar_i, p->d_Y0s);
     HIP_TRY(hipGetLastError());
   }
   // A2/A3: rollout of the local shard
@@ -539,11 +552,40 @@ extern "C" int mbd_plan_score_update(mbd_plan* p, int i, const uint32_t key_samp
   hipStream_t s = (hipStream_t)stream_;
   const int N = c.Nsample, HNu = p->HNu;
   hipLaunchKernelGGL(score_kernel, dim3(1), dim3(64), sizeof(float) * (size_t)N, s, d_rews_all,
-                     c.enable_demo ? d_logpd_all : nullptr, N, p->env->rew_xref, c.temp_sample, p->d_weights, d_rew_mean);
+                     c.enable_demo ? d_logpd_all : nullptr, N, p->env->rew_xref, c.temp_sample,
+                     c.update_method == 0 ? 1 : 0, p->d_weights, d_rew_mean);
   HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(wmean_kernel, dim3((HNu + 63) / 64), dim3(64), 0, s, p->d_weights, p->d_Y0s, N, HNu, d_Ybar_i,
-                     p->alphas[i], p->alphas_bar[i], p->alphas_bar[i - 1], c.literal_score, d_Ybar_im1);
+  const dim3 ge((HNu + 63) / 64), b64(64);
+  if (c.update_method == 3) {  // cem_update (path_integral.py:48-52)
+    const int K = N < 10 ? N : 10;
+    hipLaunchKernelGGL(cem_select_kernel, dim3(1), b64, sizeof(float) * (size_t)N, s, p->d_weights, N, K, p->d_idx);
+    hipLaunchKernelGGL(cem_mean_kernel, ge, b64, 0, s, p->d_idx, K, p->d_Y0s, HNu, d_Ybar_im1);
+  } else {  // MBD (:128-133), mppi (:33-36), cma-es (:39-45)
+    hipLaunchKernelGGL(wmean_kernel, ge, b64, 0, s, p->d_weights, p->d_Y0s, N, HNu, d_Ybar_i, p->alphas[i],
+                       p->alphas_bar[i], p->alphas_bar[i - 1], c.update_method == 0 ? c.literal_score : 0, d_Ybar_im1);
+    if (c.update_method == 2) {
+      hipLaunchKernelGGL(cma_spread_kernel, ge, b64, 0, s, p->d_weights, p->d_Y0s, N, HNu, d_Ybar_i, p->d_spread);
+      hipLaunchKernelGGL(cma_sigma_kernel, dim3(1), b64, 0, s, p->d_spread, HNu, p->d_sigma);
+    }
+  }
   HIP_TRY(hipGetLastError());
+  return MBD_OK;
+}
+
+extern "C" int mbd_plan_set_sigma(mbd_plan* p, float sigma) {
+  if (!p) return fail(MBD_ERR_INVALID, "plan is NULL");
+  if (!p->d_sigma) return fail(MBD_ERR_STATE, "not a path-integral plan (update_method == 0)");
+  HIP_TRY(hipSetDevice(p->env->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(p->d_sigma, &sigma, sizeof(float), hipMemcpyHostToDevice));
+  return MBD_OK;
+}
+extern "C" int mbd_plan_get_sigma(mbd_plan* p, float* sigma_out) {
+  if (!p || !sigma_out) return fail(MBD_ERR_INVALID, "NULL argument");
+  if (!p->d_sigma) return fail(MBD_ERR_STATE, "not a path-integral plan (update_method == 0)");
+  HIP_TRY(hipSetDevice(p->env->device));
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(sigma_out, p->d_sigma, sizeof(float), hipMemcpyDeviceToHost));
   return MBD_OK;
 }
 
@@ -581,7 +623,11 @@ extern "C" int mbd_plan_run(mbd_plan* p, const uint32_t key[2], float* mu_0ts_ou
   const int Nd = p->cfg.Ndiffuse, HNu = p->HNu;
   hipStream_t s = p->stream;
   uint32_t rng[2] = {key[0], key[1]};
-  float* cur = p->d_Ybar;  // YN = zeros (mbd_planner.py:95)
+  float* cur = p->d_Ybar;  // YN = zeros (mbd_planner.py:95; mu_0T path_integral.py:107)
+  if (p->d_sigma) {
+    const float one = 1.0f;  // sigma = 1.0 (path_integral.py:131)
+    HIP_TRY(hipMemcpy(p->d_sigma, &one, sizeof(float), hipMemcpyHostToDevice));
+  }
   HIP_TRY(hipMemsetAsync(cur, 0, sizeof(float) * HNu, s));
   HIP_TRY(hipStreamSynchronize(s));
   auto t0 = std::chrono::steady_clock::now();

@@ -581,8 +581,9 @@ __global__ __launch_bounds__(64) void car2d_rollout_kernel(Car2dParams P) {
 // Y0s[n][e] for rows [row_begin, row_begin+rows) of the global [N][HNu] tensor. One thread per threefry
 // block: legacy layout pairs element j with j+half (both outputs used); partitionable: one element.
 __global__ __launch_bounds__(256) void sample_kernel(uint32_t k0, uint32_t k1, int impl, int N, int HNu,
-                                                      float sigma, const float* __restrict__ Ybar,
-                                                      float* __restrict__ Y0s) {
+                                                      float sigma_host, const float* __restrict__ sigma_dev,
+                                                      const float* __restrict__ Ybar, float* __restrict__ Y0s) {
+  const float sigma = sigma_dev ? *sigma_dev : sigma_host;  // path-integral plans carry sigma on the device
   const uint64_t size = (uint64_t)N * (uint64_t)HNu;
   const uint64_t half = (size + 1) / 2;
   const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -663,7 +664,7 @@ __device__ __forceinline__ float wave_max(float x) {
 
 __global__ __launch_bounds__(64) void score_kernel(const float* __restrict__ rews,
                                                    const float* __restrict__ lp_demo, int N, float rew_xref,
-                                                   float temp, float* __restrict__ weights,
+                                                   float temp, int std_guard, float* __restrict__ weights,
                                                    float* __restrict__ rew_mean_out) {
   extern __shared__ __attribute__((aligned(16))) float lg[];  // logp0 [N]
   const int lane = threadIdx.x;
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(64) void score_kernel(const float* __restrict__ rew
     part = ffma(d, d, part);
   }
   float rew_std = fsqrt(wave_sum(part) / (float)N);
-  rew_std = rew_std < 1e-4f ? 1.0f : rew_std;
+  rew_std = (std_guard && rew_std < 1e-4f) ? 1.0f : rew_std;  // mbd_planner.py:112; path_integral.py:123 has none
   for (int i = lane; i < N; i += 64) lg[i] = ((rews[i] - rew_mean) / rew_std) / temp;
   if (lp_demo) {
     float mx = -__builtin_inff();
@@ -746,6 +747,61 @@ __global__ __launch_bounds__(64) void wmean_kernel(const float* __restrict__ wei
     out = Yim1 / fsqrt(alpha_bar_im1);
   }
   Ybar_im1[e] = out;
+}
+
+// ---- path-integral baselines (mbd/planners/path_integral.py:39-52) ---------------------------------------
+// cma-es: s[e] = sqrt(sum_n w_n (Y0s[n][e] - mu_t[e])^2), sequential fma over n like wmean_kernel
+__global__ __launch_bounds__(64) void cma_spread_kernel(const float* __restrict__ weights,
+                                                        const float* __restrict__ Y0s, int N, int HNu,
+                                                        const float* __restrict__ mu_t, float* __restrict__ s_out) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= HNu) return;
+  const float m = mu_t[e];
+  float acc = 0.0f;
+#pragma unroll 16
+  for (int n = 0; n < N; ++n) {
+    float d = Y0s[(size_t)n * HNu + e] - m;
+    acc = ffma(weights[n], d * d, acc);
+  }
+  s_out[e] = fsqrt(acc);
+}
+// sigma <- max(mean_e(s) * sigma, 1e-3): one wavefront, canonical reduction order
+__global__ __launch_bounds__(64) void cma_sigma_kernel(const float* __restrict__ s, int HNu, float* __restrict__ sigma) {
+  float part = 0.0f;
+  for (int i = threadIdx.x; i < HNu; i += 64) part = part + s[i];
+  float sig = (wave_sum(part) / (float)HNu) * (*sigma);
+  if (threadIdx.x == 0) *sigma = sig > 1e-3f ? sig : 1e-3f;
+}
+// cem: indices of the K (<= 10) largest weights, ties towards the higher index (argsort()[::-1][:10])
+__global__ __launch_bounds__(64) void cem_select_kernel(const float* __restrict__ weights, int N, int K,
+                                                        int* __restrict__ idx_out) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];
+  const int lane = threadIdx.x;
+  for (int i = lane; i < N; i += 64) wl[i] = weights[i];
+  for (int k = 0; k < K; ++k) {
+    float bv = -1.0f;
+    int bi = -1;
+    for (int i = lane; i < N; i += 64)
+      if (wl[i] >= bv) { bv = wl[i]; bi = i; }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      float ov = __shfl_xor(bv, off, 64);
+      int oi = __shfl_xor(bi, off, 64);
+      bool take = ov > bv || (ov == bv && oi > bi);
+      bv = take ? ov : bv;
+      bi = take ? oi : bi;
+    }
+    if (lane == 0) idx_out[k] = bi;
+    if (bi >= 0 && (bi & 63) == lane) wl[bi] = -2.0f;
+  }
+}
+__global__ __launch_bounds__(64) void cem_mean_kernel(const int* __restrict__ idx, int K, const float* __restrict__ Y0s,
+                                                      int HNu, float* __restrict__ mu_out) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= HNu) return;
+  float acc = 0.0f;
+  for (int k = 0; k < K; ++k) acc = acc + Y0s[(size_t)idx[k] * HNu + e];
+  mu_out[e] = acc / (float)K;
 }
 
 }  // namespace mbd

@@ -30,7 +30,8 @@ class PlanConfig(C.Structure):
     _fields_ = [("Nsample", C.c_int32), ("Hsample", C.c_int32), ("Ndiffuse", C.c_int32),
                 ("temp_sample", C.c_float), ("beta0", C.c_float), ("betaT", C.c_float),
                 ("enable_demo", C.c_int32), ("prng_impl", C.c_int32), ("shard_begin", C.c_int32),
-                ("shard_count", C.c_int32), ("literal_score", C.c_int32), ("reserved", C.c_int32 * 5)]
+                ("shard_count", C.c_int32), ("literal_score", C.c_int32), ("update_method", C.c_int32),
+                ("reserved", C.c_int32 * 4)]
 
 
 EXPORTS = [
@@ -38,7 +39,7 @@ EXPORTS = [
     "mbd_env_create_car2d", "mbd_env_create_model", "mbd_env_destroy", "mbd_env_info", "mbd_env_reset",
     "mbd_env_step", "mbd_env_rew_xref", "mbd_env_rollout", "mbd_plan_create", "mbd_plan_destroy",
     "mbd_plan_schedule", "mbd_plan_set_state0", "mbd_plan_sample_rollout", "mbd_plan_score_update",
-    "mbd_plan_reverse_once", "mbd_plan_run", "mbd_plan_eval", "mbd_plan_peek", "mbd_plan_kernel_time",
+    "mbd_plan_set_sigma", "mbd_plan_get_sigma", "mbd_plan_reverse_once", "mbd_plan_run", "mbd_plan_eval", "mbd_plan_peek", "mbd_plan_kernel_time",
     "mbd_plan_enable_timing",
 ]
 
@@ -83,6 +84,8 @@ def load() -> C.CDLL:
     lib.mbd_plan_set_state0.argtypes = [_vp, _vp]
     lib.mbd_plan_sample_rollout.argtypes = [_vp, _i, _u32p, _vp, _vp, _vp, _vp]
     lib.mbd_plan_score_update.argtypes = [_vp, _i, _u32p, _vp, _vp, _vp, _vp, _vp, _vp]
+    lib.mbd_plan_set_sigma.argtypes = [_vp, _f]
+    lib.mbd_plan_get_sigma.argtypes = [_vp, _fp]
     lib.mbd_plan_reverse_once.argtypes = [_vp, _i, _u32p, _vp, _vp, _vp]
     lib.mbd_plan_run.argtypes = [_vp, _u32p, _vp, _vp, _fp, C.POINTER(C.c_double)]
     lib.mbd_plan_eval.argtypes = [_vp, _vp, _fp]

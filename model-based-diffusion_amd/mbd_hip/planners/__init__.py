@@ -1,1 +1,1 @@
-from . import mbd_planner  # noqa: F401
+from . import mbd_planner, path_integral  # noqa: F401

@@ -58,13 +58,17 @@ def apply_recommended(args: Args) -> None:
 class Plan:
     """Thin owner of an ``mbd_plan`` handle."""
 
-    def __init__(self, env, args: Args, shard_begin: int = 0, shard_count: int = None, literal_score: bool = True):
+    def __init__(self, env, args, shard_begin: int = 0, shard_count: int = None, literal_score: bool = True,
+                 update_method: int = 0):
         self.lib = _capi.load()
         self.env = env
         cfg = _capi.PlanConfig()
-        cfg.Nsample, cfg.Hsample, cfg.Ndiffuse = args.Nsample, args.Hsample, args.Ndiffuse
-        cfg.temp_sample, cfg.beta0, cfg.betaT = args.temp_sample, args.beta0, args.betaT
-        cfg.enable_demo = int(args.enable_demo)
+        cfg.Nsample, cfg.Hsample = args.Nsample, args.Hsample
+        cfg.Ndiffuse = getattr(args, "Ndiffuse", None) or args.Nrefine  # path_integral.Args calls it Nrefine
+        cfg.temp_sample = args.temp_sample
+        cfg.beta0, cfg.betaT = getattr(args, "beta0", 1e-4), getattr(args, "betaT", 1e-2)
+        cfg.enable_demo = int(getattr(args, "enable_demo", False))
+        cfg.update_method = update_method
         cfg.prng_impl = prng_impl()
         cfg.shard_begin = shard_begin
         cfg.shard_count = args.Nsample if shard_count is None else shard_count
@@ -73,7 +77,7 @@ class Plan:
         h = C.c_void_p()
         _capi.check(self.lib.mbd_plan_create(env.handle, C.byref(cfg), C.byref(h)))
         self.h = h
-        self.Nd, self.H, self.Nu = args.Ndiffuse, args.Hsample, env.action_size
+        self.Nd, self.H, self.Nu = cfg.Ndiffuse, args.Hsample, env.action_size
 
     def schedule(self):
         a, ab, s = (np.zeros(self.Nd, np.float32) for _ in range(3))
@@ -100,6 +104,14 @@ class Plan:
         _capi.check(self.lib.mbd_plan_run(self.h, _capi.key_array(key), _capi.np_ptr(mu), _capi.np_ptr(rm),
                                           C.byref(rf), C.byref(secs)))
         return mu, rm, rf.value, secs.value
+
+    def get_sigma(self) -> float:
+        v = C.c_float()
+        _capi.check(self.lib.mbd_plan_get_sigma(self.h, C.byref(v)))
+        return v.value
+
+    def set_sigma(self, v: float):
+        _capi.check(self.lib.mbd_plan_set_sigma(self.h, float(v)))
 
     def eval(self, Y) -> float:
         Y = np.ascontiguousarray(Y, np.float32)

@@ -403,3 +403,63 @@ ORC_API float orc_sp_log1p(float t) { return sp_log1p_f32(t); }
 ORC_API void orc_sp_rot(const float v[3], const float q[4], float o[3]) { sp_rot(v, q, o); }
 ORC_API void orc_sp_qmul(const float a[4], const float b[4], float o[4]) { sp_qmul(a, b, o); }
 ORC_API float orc_sp_sum(const float* x, int n) { return sum_f32(x, n); }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* path-integral baselines  (mbd/planners/path_integral.py:33-52,111-127)                            */
+/*   logp0 = (rews - mean)/std/temp WITHOUT the zero-std guard (:123); weights = softmax (:124);     */
+/*   method 1 mppi   : mu = sum_n w_n Y0s_n                                       (softmax_update)    */
+/*   method 2 cma-es : mu as mppi; sigma = max(mean_e sqrt(sum_n w_n (Y0s-mu_t)^2) * sigma, 1e-3)     */
+/*   method 3 cem    : mu = mean of the 10 candidates with the largest weights    (cem_update)        */
+/* returns rews.mean(); *sigma_inout is updated for cma-es only.                                     */
+/* ------------------------------------------------------------------------------------------------ */
+ORC_API float orc_pi_update(int method, int N, int HNu, const float* rews, float temp, const float* Y0s,
+                            const float* mu_t, float* sigma_inout, float* weights, float* mu_tm1) {
+  float* logp0 = (float*)malloc(sizeof(float) * (size_t)N);
+  float rew_mean = sum_f32(rews, N) / (float)N;
+  float rew_std = __builtin_sqrtf(sumsq_dev_f32(rews, N, rew_mean) / (float)N);
+  for (int n = 0; n < N; ++n) logp0[n] = ((rews[n] - rew_mean) / rew_std) / temp;
+  float mx = max_f32(logp0, N);
+  for (int n = 0; n < N; ++n) weights[n] = sp_exp_f32(logp0[n] - mx);
+  float den = sum_f32(weights, N);
+  for (int n = 0; n < N; ++n) weights[n] = weights[n] / den;
+  if (method == 3) { /* argsort(weights)[::-1][:10]: ties resolved towards the HIGHER index */
+    int K = N < 10 ? N : 10;
+    char* used = (char*)calloc((size_t)N, 1);
+    int idx[10];
+    for (int k = 0; k < K; ++k) {
+      int best = -1;
+      for (int n = 0; n < N; ++n)
+        if (!used[n] && (best < 0 || weights[n] >= weights[best])) best = n;
+      used[best] = 1;
+      idx[k] = best;
+    }
+    for (int e = 0; e < HNu; ++e) {
+      float acc = 0.0f;
+      for (int k = 0; k < K; ++k) acc = acc + Y0s[(size_t)idx[k] * HNu + e];
+      mu_tm1[e] = acc / (float)K;
+    }
+    free(used);
+  } else {
+    for (int e = 0; e < HNu; ++e) {
+      float acc = 0.0f;
+      for (int n = 0; n < N; ++n) acc = __builtin_fmaf(weights[n], Y0s[(size_t)n * HNu + e], acc);
+      mu_tm1[e] = acc;
+    }
+    if (method == 2) {
+      float* s = (float*)malloc(sizeof(float) * (size_t)HNu);
+      for (int e = 0; e < HNu; ++e) {
+        float acc = 0.0f;
+        for (int n = 0; n < N; ++n) {
+          float d = Y0s[(size_t)n * HNu + e] - mu_t[e];
+          acc = __builtin_fmaf(weights[n], d * d, acc);
+        }
+        s[e] = __builtin_sqrtf(acc);
+      }
+      float sig = (sum_f32(s, HNu) / (float)HNu) * (*sigma_inout);
+      *sigma_inout = sig > 1e-3f ? sig : 1e-3f;
+      free(s);
+    }
+  }
+  free(logp0);
+  return rew_mean;
+}

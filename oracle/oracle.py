@@ -83,6 +83,8 @@ class Oracle:
         lib.orc_sp_qmul.argtypes = [_f32p, _f32p, _f32p]
         lib.orc_sp_sum.argtypes = [_f32p, C.c_int]
         lib.orc_sp_sum.restype = C.c_float
+        lib.orc_pi_update.argtypes = [C.c_int, C.c_int, C.c_int, _f32p, C.c_float, _f32p, _f32p, _f32p, _f32p, _f32p]
+        lib.orc_pi_update.restype = C.c_float
         lib.orc_mean_h.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p]
         lib.orc_real_bytes.restype = C.c_int
         lib.orc_model_bytes.restype = C.c_int
@@ -144,6 +146,18 @@ class Oracle:
                                       np.ascontiguousarray(Ybar_i, np.float32), alpha_i, ab_i, ab_im1,
                                       int(literal), w, out)
         return out, w, m
+
+    def pi_update(self, method, rews, Y0s, mu_t, sigma, temp):
+        """path_integral.py update rules. method: 1 mppi, 2 cma-es, 3 cem. Returns (mu, sigma, weights, rew_mean)."""
+        N = rews.shape[0]
+        HNu = int(np.prod(mu_t.shape))
+        w = np.zeros(N, np.float32)
+        out = np.zeros(mu_t.shape, np.float32)
+        sig = np.array([sigma], np.float32)
+        m = self.lib.orc_pi_update(method, N, HNu, np.ascontiguousarray(rews, np.float32), temp,
+                                   np.ascontiguousarray(Y0s, np.float32), np.ascontiguousarray(mu_t, np.float32),
+                                   sig, w, out)
+        return out, float(sig[0]), w, m
 
     # ---- car2d --------------------------------------------------------------------------------------
     def car2d_reset(self):

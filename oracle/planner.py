@@ -93,3 +93,35 @@ def run_diffusion(orc: Oracle, env: OracleEnv, seed, N, H, Nd, temp, beta0=1e-4,
     rew_final = mean_h(orc, np.ascontiguousarray(env.rollout(state0, Ybar[None])))[0]  # :179-180
     return dict(mu_0ts=np.stack(mus), rew_means=np.array(rms, np.float32), rew_final=rew_final,
                 state_init=state0)
+
+
+PI_METHODS = {"mppi": 1, "cma-es": 2, "cem": 3}
+
+
+def run_path_integral(orc: Oracle, env: OracleEnv, seed, N, H, Nrefine, temp, update_method="mppi", impl=1,
+                      max_steps=None):
+    """mbd/planners/path_integral.py:55-148 (RNG chain :57,99,144; sigma starts at 1.0 :131)."""
+    rng = orc.prng_key(seed)
+    rng, rng_reset = orc.split(rng, 2, impl)
+    state0 = env.reset(rng_reset, impl)
+    rng_exp, rng = orc.split(rng, 2, impl)
+    mu = np.zeros((H, env.Nu), np.float32)
+    sigma = np.float32(1.0)
+    mus, rms, sigmas = [], [], []
+    r = rng_exp
+    steps = 0
+    for t in range(Nrefine - 1, 0, -1):
+        keys = orc.split(r, 2, impl)
+        r, ks = keys[0], keys[1]
+        Y0s = orc.sample(ks, impl, N, H, env.Nu, 0, N, float(sigma), mu)  # :115-118
+        rews = mean_h(orc, np.ascontiguousarray(env.rollout(state0, Y0s)))  # :121
+        mu, sigma, _, rm = orc.pi_update(PI_METHODS[update_method], rews, Y0s, mu, float(sigma), temp)  # :122-125
+        mus.append(mu)
+        rms.append(rm)
+        sigmas.append(sigma)
+        steps += 1
+        if max_steps is not None and steps >= max_steps:
+            break
+    rew_final = mean_h(orc, np.ascontiguousarray(env.rollout(state0, mu[None])))[0]  # :146
+    return dict(mu_0ts=np.stack(mus), rew_means=np.array(rms, np.float32), sigmas=np.array(sigmas, np.float32),
+                rew_final=rew_final, state_init=state0)

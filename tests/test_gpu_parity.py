@@ -263,3 +263,22 @@ def test_concurrent_seed_sweep_equals_sequential_runs(gpu):
     for a, r, mu in zip(plans, rews, mus):
         r_seq, det = run_diffusion(a, return_details=True)
         assert np.array_equal(mu, det["mu_0ts"]) and np.float32(r) == np.float32(r_seq)
+
+
+@pytest.mark.parametrize("method", ["mppi", "cma-es", "cem"])
+@pytest.mark.parametrize("name,N,H,Nr", [("hopper", 256, 50, 12), ("humanoidrun", 128, 20, 8)])
+def test_path_integral_baselines_end_to_end(gpu, orc, method, name, N, H, Nr):
+    """mbd/planners/path_integral.py (MPPI / CMA-ES / CEM) on the same rollout kernel —
+    whole runs, bit for bit against the oracle (mu history, per-step mean rewards, final sigma, rew_final)."""
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.path_integral import Args, run_path_integral
+    from oracle import planner as op
+    args = Args(seed=2, env_name=name, Nsample=N, Hsample=H, Nrefine=Nr, temp_sample=0.1,
+                update_method=method, disable_recommended_params=True)
+    rew, det = run_path_integral(args, return_details=True)
+    env = get_env(name)
+    ref = op.run_path_integral(orc, _oenv(orc, env), 2, N, H, Nr, 0.1, method)
+    assert np.array_equal(det["mu_0ts"], ref["mu_0ts"]), method
+    assert np.array_equal(det["rew_means"], ref["rew_means"])
+    assert np.float32(det["sigma_final"]) == np.float32(ref["sigmas"][-1])
+    assert np.float32(rew) == np.float32(ref["rew_final"])
