@@ -50,14 +50,16 @@ typedef enum mbd_status {
 #define MBD_MAX_LINKS 16
 #define MBD_MAX_Q 40
 #define MBD_MAX_ACT 24
-#define MBD_MAX_COL 8
+#define MBD_MAX_COL 16
 #define MBD_MAX_TRACK 8
 
 enum mbd_reward_kind {
   MBD_REW_HUMANOIDRUN = 0,   /* mbd/envs/humanoidrun.py:46-51                                        */
-  MBD_REW_HOPPER = 1,        /* mbd/envs/hopper.py:57-65                                             */
+  MBD_REW_HOPPER = 1,        /* mbd/envs/hopper.py:57-65 and walker2d.py:57-62: x - clip(|z - p0|,-1,1)*p1,
+                                reward_params = (p0, p1) = (1.0, 0.5) hopper / (1.1, 0.5) walker2d     */
   MBD_REW_HALFCHEETAH = 2,   /* brax.envs.half_cheetah (absent from the reference tree)              */
-  MBD_REW_HUMANOIDTRACK = 3  /* mbd/envs/humanoidtrack.py:87-96 (computed from the INCOMING state)   */
+  MBD_REW_HUMANOIDTRACK = 3, /* mbd/envs/humanoidtrack.py:87-96 (computed from the INCOMING state)   */
+  MBD_REW_HUMANOIDSTANDUP = 4 /* mbd/envs/humanoidstandup.py:50-56                                    */
 };
 
 typedef struct mbd_model {

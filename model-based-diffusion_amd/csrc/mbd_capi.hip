@@ -112,6 +112,8 @@ int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B
   hipLaunchKernelGGL((rollout_kernel<LPS, ISO, SL, CH, COL>), grid, block, 0, stream, P)
   if (env->lps == 16 && iso && !env->slides && env->max_children <= 3 && env->max_col <= 1) {
     MBD_LAUNCH(16, true, false, 3, 1);  // the humanoid (metric config)
+  } else if (env->lps == 16 && iso && !env->slides && env->max_children <= 3 && env->max_col <= 5) {
+    MBD_LAUNCH(16, true, false, 3, 5);  // humanoidstandup: up to 5 sphere colliders on one link
   } else if (env->lps == 16) {
     if (iso) MBD_LAUNCH(16, true, true, 4, 2); else MBD_LAUNCH(16, false, true, 4, 2);
   } else if (env->lps == 8) {
@@ -303,7 +305,14 @@ extern "C" int mbd_env_create_model(const char* env_name, int device, const mbd_
     if (ncl[l] > e->max_col) e->max_col = ncl[l];
   }
   if (e->max_children > kMaxChildren) { delete e; return fail(MBD_ERR_UNSUPPORTED, "a link has %d children > %d", e->max_children, kMaxChildren); }
-  if (e->max_col > 2) { delete e; return fail(MBD_ERR_UNSUPPORTED, "a link has more than 2 sphere colliders"); }
+  {
+    const bool standup_shape = e->lps == 16 && m.iso_inertia && !e->slides && e->max_children <= 3;
+    if (e->max_col > (standup_shape ? 5 : 2)) {
+      const int mc = e->max_col;
+      delete e;
+      return fail(MBD_ERR_UNSUPPORTED, "a link has %d sphere colliders: more than this kernel family is built for", mc);
+    }
+  }
   HIP_TRY(hipMalloc(&e->d_model, sizeof(mbd_model_t)));
   HIP_TRY(hipMemcpy(e->d_model, &e->model, sizeof(mbd_model_t), hipMemcpyHostToDevice));
   if (xref) {

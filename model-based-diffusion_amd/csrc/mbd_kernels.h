@@ -488,9 +488,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       if (rkind == MBD_REW_HUMANOIDRUN) {
         rew = o1.x * 1.0f - fclip(fabs_(o1.z - 1.3f), -1.0f, 1.0f) * 1.0f - fabs_(o1.y) * 0.1f;
       } else if (rkind == MBD_REW_HOPPER) {
-        rew = o1.x - fclip(fabs_(o1.z - 1.0f), -1.0f, 1.0f) * 0.5f;
+        rew = o1.x - fclip(fabs_(o1.z - rp0), -1.0f, 1.0f) * rp1;
       } else if (rkind == MBD_REW_HALFCHEETAH) {
         rew = rp0 * ((o1.x - o0.x) / dt_ctrl) - rp1 * ctrl_cost;
+      } else if (rkind == MBD_REW_HUMANOIDSTANDUP) {
+        rew = 1.5f - fclip(fabs_(o1.z - 1.3f), -2.0f, 1.0f) - fabs_(o1.x) * 0.1f - fabs_(o1.y) * 0.1f;
       } else {
         rew = 1.0f + (-fabs_(v0.x - 1.6f) - fabs_(o0.z - 1.3f) - fabs_(o0.y) * 0.1f);
       }

@@ -10,7 +10,12 @@ SPECS = {
                           drop_suffix="_ref",
                           track=("torso", "left_thigh", "right_thigh", "left_shin", "right_shin")),
     # mbd/envs/hopper.py:12-18 (_reset_noise_scale 5e-3, n_frames 20); XML re-authored (see assets/hopper.xml)
-    "hopper": dict(xml="hopper.xml", from_reference=False, n_frames=20, reset_noise=5e-3),
+    "hopper": dict(xml="hopper.xml", from_reference=False, n_frames=20, reset_noise=5e-3, reward_params=(1.0, 0.5)),
+    # mbd/envs/walker2d.py:11-18,57-62 (same shape as the hopper; XML re-authored, see assets/walker2d.xml)
+    "walker2d": dict(xml="walker2d.xml", from_reference=False, n_frames=20, reset_noise=5e-3,
+                     reward_params=(1.1, 0.5)),
+    # mbd/envs/humanoidstandup.py:14-27,50-56: the humanoid lying on the floor, 15 sphere colliders
+    "humanoidstandup": dict(xml="humanoidstandup.xml", from_reference=True, n_frames=7, reset_noise=0.01),
     # brax.envs.half_cheetah (absent): n_frames 16 @ 0.003125 s, reset noise 0.1, forward_reward_weight 1,
     # ctrl_cost_weight 0.1 — recollection, unpinned
     "halfcheetah": dict(xml="halfcheetah.xml", from_reference=False, n_frames=16, reset_noise=0.1,
@@ -18,4 +23,4 @@ SPECS = {
 }
 
 # names mbd.envs.get_env knows (mbd/envs/__init__.py:13-33) that are outside the hot-path scope
-OUT_OF_SCOPE = ("pushT", "humanoidstandup", "walker2d", "cartpole", "ant")
+OUT_OF_SCOPE = ("pushT", "cartpole", "ant")

@@ -410,8 +410,8 @@ static real env_step(const mbd_model_t* m, xf_t* x, mo_t* xd, const float* actio
   switch (m->reward_kind) {
     case MBD_REW_HUMANOIDRUN: /* humanoidrun.py:46-51 */
       return o1[0] * R(1) - sp_clip(sp_abs(o1[2] - R(1.3)), R(-1), R(1)) * R(1) - sp_abs(o1[1]) * R(0.1);
-    case MBD_REW_HOPPER: /* hopper.py:57-65 */
-      return o1[0] - sp_clip(sp_abs(o1[2] - R(1.0)), R(-1), R(1)) * R(0.5);
+    case MBD_REW_HOPPER: /* hopper.py:57-65 (z0 = 1.0) / walker2d.py:57-62 (z0 = 1.1) */
+      return o1[0] - sp_clip(sp_abs(o1[2] - R(m->reward_params[0])), R(-1), R(1)) * R(m->reward_params[1]);
     case MBD_REW_HALFCHEETAH: { /* brax half_cheetah: forward velocity - 0.1*|a|^2 */
       real ctrl = 0;
       for (int a = 0; a < m->n_act; ++a) ctrl += R(action[a]) * R(action[a]);
@@ -420,6 +420,8 @@ static real env_step(const mbd_model_t* m, xf_t* x, mo_t* xd, const float* actio
     }
     case MBD_REW_HUMANOIDTRACK: /* humanoidtrack.py:87-96: from the INCOMING state */
       return R(1) + (-sp_abs(v0[0] - R(1.6)) - sp_abs(o0[2] - R(1.3)) - sp_abs(o0[1]) * R(0.1));
+    case MBD_REW_HUMANOIDSTANDUP: /* humanoidstandup.py:50-56 */
+      return R(1.5) - sp_clip(sp_abs(o1[2] - R(1.3)), R(-2), R(1)) - sp_abs(o1[0]) * R(0.1) - sp_abs(o1[1]) * R(0.1);
     default: return 0;
   }
 }

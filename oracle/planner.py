@@ -24,7 +24,7 @@ class OracleEnv:
         q = np.array(self.init_q, np.float32)
         qd = np.zeros(m.n_qd, np.float32)
         s = np.float32(m.reset_noise)
-        if s > 0:
+        if s > 0:  # humanoidrun.py:21-27, hopper.py:22-28, walker2d.py:21-27, humanoidstandup.py:21-27
             keys = self.orc.split(key, 3, impl)
             q = (q + self.orc.uniform(keys[1], m.n_q, -s, s, impl)).astype(np.float32)
             if self.name == "halfcheetah":

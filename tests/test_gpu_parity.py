@@ -45,7 +45,7 @@ def test_prng_split_and_reset(gpu, orc, impl, monkeypatch):
     assert np.array_equal(key, orc.prng_key(7))
     for num in (2, 3):
         assert np.array_equal(gpu.prng_split(key, num, impl), orc.split(key, num, impl))
-    for name in ("humanoidrun", "hopper", "halfcheetah", "humanoidtrack", "car2d"):
+    for name in ("humanoidrun", "hopper", "halfcheetah", "humanoidtrack", "walker2d", "humanoidstandup", "car2d"):
         env = get_env(name)
         st = env.reset(key)
         ref = _oenv(orc, env).reset(key, impl)
@@ -54,7 +54,8 @@ def test_prng_split_and_reset(gpu, orc, impl, monkeypatch):
 
 @pytest.mark.parametrize("name,B,H,sigma", [("humanoidrun", 96, 50, 0.6), ("humanoidrun", 1, 3, 0.3),
                                             ("humanoidtrack", 64, 50, 0.4), ("hopper", 80, 50, 0.5),
-                                            ("halfcheetah", 72, 50, 0.5), ("car2d", 128, 30, 0.5),
+                                            ("halfcheetah", 72, 50, 0.5), ("walker2d", 40, 50, 0.5),
+                                            ("humanoidstandup", 36, 50, 0.5), ("car2d", 128, 30, 0.5),
                                             ("car2d", 3, 50, 1.0)])
 def test_rollout_bitexact(gpu, orc, name, B, H, sigma):
     from mbd_hip.envs import get_env
@@ -138,6 +139,11 @@ def test_reverse_once_humanoidrun(gpu, orc, impl, monkeypatch):
 
 def test_reverse_once_hopper(gpu, orc):
     _one_step(gpu, orc, "hopper", 512, 50, 100, 0.1, 1, False, i=40)
+
+
+def test_reverse_once_walker2d_and_standup(gpu, orc):
+    _one_step(gpu, orc, "walker2d", 128, 50, 100, 0.1, 1, False, i=60)
+    _one_step(gpu, orc, "humanoidstandup", 96, 50, 100, 0.1, 1, False, i=90)
 
 
 def test_reverse_once_halfcheetah(gpu, orc):

@@ -117,7 +117,8 @@ def test_humanoid_zero_action_feet_rest_on_floor(orc):
     assert abs(r - (pos[0, 0] - min(abs(pos[0, 2] - 1.3), 1.0) - 0.1 * abs(pos[0, 1]))) < 1e-6
 
 
-@pytest.mark.parametrize("name", ["humanoidrun", "humanoidtrack", "hopper", "halfcheetah"])
+@pytest.mark.parametrize("name", ["humanoidrun", "humanoidtrack", "hopper", "halfcheetah", "walker2d",
+                                  "humanoidstandup"])
 def test_rollouts_stay_finite_and_actions_saturate(orc, name):
     m = load_model(name)
     ms = m.to_struct()
