@@ -25,7 +25,7 @@ for p in (ROOT, os.path.join(ROOT, "model-based-diffusion_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-N_PER_GPU = 1024
+N_PER_GPU = int(os.environ.get("MBD_BENCH_N", "1024"))  # 1024 = the metric config; other values: experiments only
 H, ND, TEMP, ENV = 50, 100, 0.1, "humanoidrun"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 

@@ -18,6 +18,7 @@ using namespace mbd;
 namespace {
 
 thread_local std::string g_err;
+unsigned long long* g_dbg_clock = nullptr;  // set by mbd_debug_set_clock_buffer (tools/probes only)
 
 int fail(int code, const char* fmt, ...) {
   char buf[512];
@@ -104,7 +105,7 @@ int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B
     HIP_TRY(hipGetLastError());
     return MBD_OK;
   }
-  RolloutParams P{env->d_model, d_state0, d_us, d_rewss, d_rews, d_xpos, d_state_final, B, H};
+  RolloutParams P{env->d_model, d_state0, d_us, d_rewss, d_rews, d_xpos, d_state_final, B, H, g_dbg_clock};
   const bool iso = env->model.iso_inertia != 0;
   const int spw = 64 / env->lps;
   dim3 grid((B + spw - 1) / spw), block(64);
@@ -215,6 +216,8 @@ int check_model(const mbd_model_t& m) {
 // ==================================================================================================
 extern "C" const char* mbd_last_error(void) { return g_err.c_str(); }
 extern "C" int mbd_version(void) { return 1; }
+// undocumented probe hook (not in include/mbd_hip.h): per-workgroup start/end ticks of the rollout kernel
+extern "C" int mbd_debug_set_clock_buffer(void* d_buf) { g_dbg_clock = (unsigned long long*)d_buf; return MBD_OK; }
 extern "C" int mbd_device_count(int* count) {
   if (!count) return fail(MBD_ERR_INVALID, "count is NULL");
   *count = device_count_quiet();

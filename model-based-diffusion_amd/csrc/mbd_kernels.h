@@ -34,6 +34,7 @@ struct RolloutParams {
   float* xpos;               // [B][H][K][3] or nullptr
   float* state_final;        // [B][L][13] or nullptr
   int B, H;
+  unsigned long long* dbg_clock;  // nullptr, or [grid][3] = (start tick, end tick, HW_ID|XCC<<32) (tools/probes)
 };
 
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
@@ -139,6 +140,7 @@ __device__ __forceinline__ v3 crossz(v3 a) { return v3{a.y, -a.x, 0.0f}; }
 template <int LPS, bool ISO, bool SLIDES, int MAXCH, int MAXCOL>
 __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
   const mbd_model_t* __restrict__ M = P.model;
+  const unsigned long long dbg_t0 = P.dbg_clock ? __builtin_amdgcn_s_memtime() : 0ull;
   const int lane = threadIdx.x & 63;
   const int base = lane & ~(LPS - 1);
   const int l_raw = lane & (LPS - 1);
@@ -458,8 +460,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       for (int j = 0; j < MAXCOL; ++j) {
         v3 rc = sub(con_pos[j], p);
         v3 vpt = add(v, cross(w, rc));
-        v3 vprev = add(v_old, cross(w_old, rc));
-        float vn = vpt.z, vn_prev = vprev.z;
+        // restitution needs the pre-solve normal velocity only when elasticity != 0 (wave-uniform); with
+        // e = 0 the term min(-e*vn_prev, 0) is exactly 0
+        float vn_prev = 0.0f;
+        if (elast != 0.0f) vn_prev = add(v_old, cross(w_old, rc)).z;
+        float vn = vpt.z;
         v3 vt = mk3(vpt.x, vpt.y, 0.0f);
         float vtn = fsqrt(ffma(vt.x, vt.x, vt.y * vt.y));
         float inv = 1.0f / (vtn + 1e-10f);
@@ -506,6 +511,12 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
 #pragma unroll
     for (int k = 0; k < 3; ++k) { u_rot[k] = un_rot[k]; u_sl[k] = un_sl[k]; }
   }  // control steps
+  if (P.dbg_clock && lane == 0) {
+    P.dbg_clock[blockIdx.x * 3 + 0] = dbg_t0;
+    P.dbg_clock[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memtime();
+    P.dbg_clock[blockIdx.x * 3 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |
+                                      ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
+  }
   if (l_raw == 0 && b_ok && P.rews) P.rews[b] = rew_sum / (float)H;
   if (P.state_final && link_ok && b_ok) {
     float* o = P.state_final + ((size_t)b * L + l) * MBD_LINK_STATE;
