@@ -118,8 +118,7 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if rank == 0:
-        __graft_entry__.build()
+    __graft_entry__.build()  # serialised across ranks by a file lock; a no-op when the library is fresh
     distributed = world > 1
     backend = os.environ.get("MBD_DIST_BACKEND", "nccl")  # "gloo": 2-rank dry runs on a single-GPU box
     n_dev = torch.cuda.device_count()
