@@ -135,6 +135,10 @@ class Car2d(_EnvBase):
         st = super().reset(np.zeros(2, np.uint32) if rng is None else rng)
         return st.replace(obs=st.pipeline_state.copy())
 
+    def step(self, state: State, action) -> State:  # car2d.py:86: obs = q
+        st = super().step(state, action)
+        return st.replace(obs=np.asarray(st.pipeline_state).copy())
+
     def eval_xref_logpd(self, xs) -> np.float32:
         """car2d.py:95-102 for ONE trajectory xs [H,3] (host; the planner uses the batched kernel)."""
         xs = np.asarray(xs, np.float32)
@@ -180,6 +184,74 @@ class RigidBodyEnv(_EnvBase):
     def _next_done(self, state):
         # humanoidtrack abuses `done` as a time counter (humanoidtrack.py:71,81)
         return np.float32(state.done + 1) if self.env_name == "humanoidtrack" else np.float32(0.0)
+
+    # ---- kinematics.inverse on the host (observations only; the planner never reads obs) ---------------
+    def generalized(self, pipeline_state):
+        """(q, qd) from a [L,13] COM-frame state: free root = link-frame pose / velocity; slides = anchor
+        offset / relative anchor velocity along the slide axes; hinges = joint-frame Euler angles (x, y', z'')
+        times the MJCF axis handedness and the relative angular velocity projected on the gimbal axes."""
+        from ..mjcf import _q2mat, _qmul
+        F = self.sys.fields
+        s = np.asarray(pipeline_state, np.float64).reshape(-1, LINK_STATE)
+        q = np.zeros(self.sys.q_size())
+        qd = np.zeros(self.sys.qd_size())
+        for l in range(self.sys.n_links):
+            p, r, v, w = s[l, :3], s[l, 3:7], s[l, 7:10], s[l, 10:13]
+            R = _q2mat(r)
+            qi, di = int(F["q_idx"][l]), int(F["qd_idx"][l])
+            if F["n_rot"][l] < 0:
+                c = R @ np.asarray(F["com"][l], float)
+                q[qi:qi + 3], q[qi + 3:qi + 7] = p - c, r
+                qd[di:di + 3], qd[di + 3:di + 6] = v - np.cross(w, c), w
+                continue
+            par = int(F["parent"][l])
+            if par >= 0:
+                Pp, Pr, Pv, Pw = s[par, :3], s[par, 3:7], s[par, 7:10], s[par, 10:13]
+            else:
+                Pp, Pr, Pv, Pw = np.zeros(3), np.array([1.0, 0, 0, 0]), np.zeros(3), np.zeros(3)
+            RP = _q2mat(Pr)
+            ap = Pp + RP @ np.asarray(F["ap_pos"][l], float)
+            ac = p + R @ np.asarray(F["ac_pos"][l], float)
+            A = _q2mat(_qmul(Pr, np.asarray(F["ap_rot"][l], float)))
+            Cm = _q2mat(_qmul(r, np.asarray(F["ac_rot"][l], float)))
+            Xp, Yp, Zp = A[:, 0], A[:, 1], A[:, 2]
+            Xc, Yc, Zc = Cm[:, 0], Cm[:, 1], Cm[:, 2]
+            ang = [np.arctan2(-Zc @ Yp, Zc @ Zp), np.arcsin(np.clip(Zc @ Xp, -1, 1)), np.arctan2(-Yc @ Xp, Xc @ Xp)]
+            n1 = np.cross(Zc, Xp)
+            axes = [Xp, n1 / (np.linalg.norm(n1) + 1e-12), Zc]
+            rel_w = w - Pw
+            rel_v = (v + np.cross(w, ac - p)) - (Pv + np.cross(Pw, ap - Pp))
+            ns, nr = int(F["n_slide"][l]), int(F["n_rot"][l])
+            for k in range(ns):
+                sk = A @ np.asarray(F["slide_axis"][l][k], float)
+                q[qi + k], qd[di + k] = (ac - ap) @ sk, rel_v @ sk
+            for k in range(nr):
+                sg = float(F["rot_sign"][l][k])
+                q[qi + ns + k], qd[di + ns + k] = sg * ang[k], sg * (rel_w @ axes[k])
+        return q.astype(np.float32), qd.astype(np.float32)
+
+    def _get_obs(self, pipeline_state) -> np.ndarray:
+        q, qd = self.generalized(pipeline_state)
+        if self.env_name in ("hopper", "walker2d"):  # hopper.py:49-55 / walker2d.py:49-55
+            pos = q.copy()
+            pos[1] = self.link_positions(pipeline_state)[0, 2]
+            return np.concatenate([pos, np.clip(qd, -10, 10)]).astype(np.float32)
+        if self.env_name == "halfcheetah":  # brax half_cheetah: the root x position is excluded
+            return np.concatenate([q[1:], qd]).astype(np.float32)
+        return np.concatenate([q, qd]).astype(np.float32)  # humanoidrun.py:43-44 etc.
+
+    def reset(self, rng) -> State:
+        st = super().reset(rng)
+        return st.replace(obs=self._get_obs(st.pipeline_state))
+
+    def step(self, state: State, action) -> State:
+        st = super().step(state, action)
+        return st.replace(obs=self._get_obs(st.pipeline_state))
+
+    @property
+    def observation_size(self) -> int:
+        n = self.sys.q_size() + self.sys.qd_size()
+        return n - 1 if self.env_name == "halfcheetah" else n
 
     def link_positions(self, pipeline_state) -> np.ndarray:
         """x.pos of every link (world position of the link-frame origin) from a [L,13] state."""
