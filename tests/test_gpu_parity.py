@@ -288,3 +288,56 @@ def test_path_integral_baselines_end_to_end(gpu, orc, method, name, N, H, Nr):
     assert np.array_equal(det["rew_means"], ref["rew_means"])
     assert np.float32(det["sigma_final"]) == np.float32(ref["sigmas"][-1])
     assert np.float32(rew) == np.float32(ref["rew_final"])
+
+
+def test_demo_path_through_the_sharded_step_loop(gpu):
+    """BASELINE config 5 shape (humanoidtrack, enable_demo): the Python step loop used for multi-GPU runs
+    packs [rews, demo log-density] in ONE exchange buffer; world size 1 must equal mbd_plan_run, and a
+    2-shard emulation on one GPU must equal the unsharded step."""
+    import torch
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.mbd_planner import Args, Plan, reverse_distributed
+    args = Args(env_name="humanoidtrack", Nsample=128, Hsample=50, Ndiffuse=8, temp_sample=0.1, enable_demo=True,
+                disable_recommended_params=True, not_render=True)
+    env = get_env("humanoidtrack")
+    st = env.reset(gpu.prng_key(0))
+    key = gpu.prng_key(5)
+    p1 = Plan(env, args)
+    p1.set_state0(st)
+    mu1, rm1, _, _ = p1.run(key)
+    p2 = Plan(env, args)
+    p2.set_state0(st)
+    mu2, rm2 = reverse_distributed(p2, key, 0)
+    assert np.array_equal(mu1, mu2.cpu().numpy()) and np.array_equal(rm1, rm2.cpu().numpy())
+    # two shards, manual gather of both rows
+    N, H, i = 128, 50, 5
+    ks = gpu.key_array(gpu.prng_split(key, 2)[1])
+    Ybar = torch.tensor(mu1[2].reshape(-1), device="cuda")
+    res = []
+    for shards in ([(0, N)], [(0, 64), (64, 64)]):
+        plans = [Plan(env, args, shard_begin=b, shard_count=c) for b, c in shards]
+        allv = torch.zeros((2, N), device="cuda")
+        for p, (b, c) in zip(plans, shards):
+            p.set_state0(st)
+            loc = torch.zeros((2, c), device="cuda")
+            gpu.check(p.lib.mbd_plan_sample_rollout(p.h, i, ks, Ybar.data_ptr(), loc[0].data_ptr(), loc[1].data_ptr(), None))
+            torch.cuda.synchronize()
+            allv[:, b:b + c] = loc
+        out, rm = torch.zeros(H * 17, device="cuda"), torch.zeros(1, device="cuda")
+        gpu.check(plans[-1].lib.mbd_plan_score_update(plans[-1].h, i, ks, Ybar.data_ptr(), allv[0].data_ptr(),
+                                                      allv[1].data_ptr(), out.data_ptr(), rm.data_ptr(), None))
+        torch.cuda.synchronize()
+        res.append((out.cpu().numpy(), rm.item()))
+        for p in plans:
+            p.close()
+    assert np.array_equal(res[0][0], res[1][0]) and res[0][1] == res[1][1]
+
+
+def test_env_step_produces_observations(gpu):
+    from mbd_hip.envs import get_env
+    for name in ("humanoidrun", "hopper", "car2d"):
+        env = get_env(name)
+        st = env.reset(gpu.prng_key(1))
+        assert st.obs is not None and st.obs.shape == (env.observation_size,)
+        st2 = env.step(st, np.zeros(env.action_size, np.float32))
+        assert st2.obs.shape == (env.observation_size,) and np.isfinite(st2.obs).all()
