@@ -240,6 +240,9 @@ def run_diffusion(args: Args, device: int = None, return_details: bool = False):
         path = os.path.join(os.getcwd(), "results", args.env_name)
         os.makedirs(path, exist_ok=True)
         np.save(os.path.join(path, "mu_0ts.npy"), mu)
+        # stand-in for rollout.html / rollout.png (:157-178): the replayed final plan as arrays
+        from ..utils import rollout_states
+        np.savez_compressed(os.path.join(path, "rollout_states.npz"), **rollout_states(env, state_init, mu[-1]))
     plan.close()
     if return_details:
         return rew_final, dict(mu_0ts=mu, rew_means=rew_means, loop_seconds=secs, state_init=state_init,

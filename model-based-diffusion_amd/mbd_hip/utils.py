@@ -21,3 +21,20 @@ def rollout_us(env, state, us):
 
 def eval_us(env, state, us):
     return rollout_us(env, state, us)[0]
+
+
+def rollout_states(env, state, us):
+    """The state after every control step of ONE action sequence (what the reference's render_us collects
+    for the HTML viewer, utils.py:23-33), as plain arrays: pipeline states [H+1, ...] (incl. the initial
+    one), rewards [H] and, for rigid-body envs, world link positions [H+1, L, 3] (x.pos)."""
+    us = np.ascontiguousarray(us, np.float32)
+    states, rews = [np.asarray(state.pipeline_state, np.float32).copy()], []
+    st = state
+    for t in range(us.shape[0]):
+        st = env.step(st, us[t])
+        states.append(np.asarray(st.pipeline_state, np.float32).copy())
+        rews.append(np.float32(st.reward))
+    out = dict(pipeline_states=np.stack(states), rewards=np.asarray(rews, np.float32))
+    if hasattr(env, "link_positions"):
+        out["link_positions"] = np.stack([env.link_positions(s) for s in states])
+    return out

@@ -341,3 +341,21 @@ def test_env_step_produces_observations(gpu):
         assert st.obs is not None and st.obs.shape == (env.observation_size,)
         st2 = env.step(st, np.zeros(env.action_size, np.float32))
         assert st2.obs.shape == (env.observation_size,) and np.isfinite(st2.obs).all()
+
+
+def test_render_outputs_mu0ts_and_replay(gpu, tmp_path, monkeypatch):
+    """N1: without not_render the run leaves results/{env}/mu_0ts.npy (the array vis_diffusion.py:22 loads)
+    and the replayed final plan; replaying through env.step equals the batched rollout kernel."""
+    from mbd_hip.planners.mbd_planner import Args, run_diffusion
+    monkeypatch.chdir(tmp_path)
+    args = Args(seed=0, env_name="hopper", Nsample=64, Hsample=20, Ndiffuse=6, temp_sample=0.1,
+                disable_recommended_params=True, not_render=False)
+    rew, det = run_diffusion(args, return_details=True)
+    mu = np.load(tmp_path / "results" / "hopper" / "mu_0ts.npy")
+    assert mu.shape == (5, 20, 3) and np.array_equal(mu, det["mu_0ts"])
+    rs = np.load(tmp_path / "results" / "hopper" / "rollout_states.npz")
+    assert rs["pipeline_states"].shape == (21, 4, 13) and rs["link_positions"].shape == (21, 4, 3)
+    s = np.float32(0)
+    for r in rs["rewards"]:
+        s = np.float32(s + r)
+    assert np.float32(s / np.float32(20)) == np.float32(rew)   # step-by-step replay == rollout kernel
