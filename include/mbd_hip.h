@@ -59,7 +59,8 @@ enum mbd_reward_kind {
                                 reward_params = (p0, p1) = (1.0, 0.5) hopper / (1.1, 0.5) walker2d     */
   MBD_REW_HALFCHEETAH = 2,   /* brax.envs.half_cheetah (absent from the reference tree)              */
   MBD_REW_HUMANOIDTRACK = 3, /* mbd/envs/humanoidtrack.py:87-96 (computed from the INCOMING state)   */
-  MBD_REW_HUMANOIDSTANDUP = 4 /* mbd/envs/humanoidstandup.py:50-56                                    */
+  MBD_REW_HUMANOIDSTANDUP = 4, /* mbd/envs/humanoidstandup.py:50-56                                   */
+  MBD_REW_CARTPOLE = 5       /* mbd/envs/cartpole.py:45: cos(q[1]) - |qd[0]| (hinge of link 1, slide of link 0) */
 };
 
 typedef struct mbd_model {
@@ -94,6 +95,8 @@ typedef struct mbd_model {
   float rot_stiff[MBD_MAX_LINKS][3], rot_damp[MBD_MAX_LINKS][3];
   float rot_sign[MBD_MAX_LINKS][3]; /* q_k = rot_sign_k * euler_k (handedness of the MJCF axes)    */
   float slide_axis[MBD_MAX_LINKS][3][3]; /* slide axes in the joint frame                          */
+  float slide_lo[MBD_MAX_LINKS][3], slide_hi[MBD_MAX_LINKS][3]; /* slide limits (metres)            */
+  float slide_damp[MBD_MAX_LINKS][3];    /* MJCF joint damping of the slide dofs                    */
   /* actuators (brax.actuator.to_tau: clip to ctrlrange, * gear, scatter to the dof)               */
   int32_t act_link[MBD_MAX_ACT];
   int32_t act_slot[MBD_MAX_ACT]; /* 0..2 hinge k, 3..5 slide k                                     */

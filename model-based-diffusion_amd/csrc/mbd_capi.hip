@@ -196,9 +196,6 @@ int check_model(const mbd_model_t& m) {
   if (m.n_frames < 1) return fail(MBD_ERR_INVALID, "n_frames=%d", m.n_frames);
   for (int l = 0; l < m.n_links; ++l) {
     if (m.parent[l] >= l) return fail(MBD_ERR_INVALID, "link %d: parent %d must precede it", l, m.parent[l]);
-    if (m.n_rot[l] == 0)
-      return fail(MBD_ERR_UNSUPPORTED, "link %d: joints without a hinge dof (weld / pure slide) are outside "
-                                       "the hot-path scope", l);
     if (m.n_rot[l] < 0 && m.parent[l] >= 0) return fail(MBD_ERR_INVALID, "free joint below the root");
   }
   // at most one actuator per dof (the kernel keeps one (index, gear) pair per dof slot)
@@ -300,7 +297,7 @@ extern "C" int mbd_env_create_model(const char* env_name, int device, const mbd_
   int nch[MBD_MAX_LINKS] = {0}, ncl[MBD_MAX_LINKS] = {0};
   for (int l = 0; l < m.n_links; ++l) {
     if (m.parent[l] >= 0) nch[m.parent[l]]++;
-    if (m.n_slide[l] > 0) e->slides = true;
+    if (m.n_slide[l] > 0 || m.n_rot[l] == 0) e->slides = true;  // slides and welds both need the generic kernels
   }
   for (int k = 0; k < m.n_col; ++k) ncl[m.col_link[k]]++;
   for (int l = 0; l < m.n_links; ++l) {

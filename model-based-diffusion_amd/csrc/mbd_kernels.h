@@ -66,7 +66,7 @@ __device__ __forceinline__ v3 iinv(const Inert<ISO>& in, q4 r, v3 v) {
 struct JointFrames {
   v3 ap, ac;
   v3x2 anchor;  // (ap, ac) packed
-  q4 aprot;
+  q4 aprot, acrot;
   v3 Xp, Xc, Yc, Zc, ax1;
   float ang0, ang1, ang2;
 };
@@ -86,6 +86,7 @@ __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp,
   f.ap = lo3(anchor); f.ac = hi3(anchor);
   f.anchor = anchor;
   f.aprot = lo4(arot);
+  f.acrot = q4{arot.w.y, arot.x.y, arot.y.y, arot.z.y};
   struct { v3 X, Y, Z; } A{lo3(AX.X), lo3(AX.Y), lo3(AX.Z)}, C{hi3(AX.X), hi3(AX.Y), hi3(AX.Z)};
   f.Xp = A.X; f.Xc = C.X; f.Yc = C.Y; f.Zc = C.Z;
   // sin b = Zc.Xp; (sin a, cos a) and (sin c, cos c) both have length cos b: one reciprocal for all
@@ -180,6 +181,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
   const int zero_lane = M->n_rot[0] < 0 ? base : (L < LPS ? base + L : -1);  // a lane contributing zeros
   float lim_lo[3], lim_hi[3], stiff[3], damp[3];
   v3 saxis[3];
+  float sl_lo[3], sl_hi[3], sl_damp[3];
   int act_rot[3], act_sl[3];
   float gear_rot[3], gear_sl[3], alo_rot[3], ahi_rot[3], alo_sl[3], ahi_sl[3];
 #pragma unroll
@@ -187,6 +189,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
     lim_lo[k] = M->rot_lo[l][k]; lim_hi[k] = M->rot_hi[l][k];
     stiff[k] = M->rot_stiff[l][k]; damp[k] = M->rot_damp[l][k];
     saxis[k] = mk3(M->slide_axis[l][k][0], M->slide_axis[l][k][1], M->slide_axis[l][k][2]);
+    sl_lo[k] = M->slide_lo[l][k]; sl_hi[k] = M->slide_hi[l][k]; sl_damp[k] = M->slide_damp[l][k];
     act_rot[k] = -1; act_sl[k] = -1;
     gear_rot[k] = gear_sl[k] = 0.0f; alo_rot[k] = alo_sl[k] = 0.0f; ahi_rot[k] = ahi_sl[k] = 0.0f;
   }
@@ -317,9 +320,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             v3 s = rot(saxis[k], f.aprot);
-            F = axpy(k < ns && is_joint ? tau_sl[k] : 0.0f, s, F);
-            float cf = k < ns ? -dot(rel_v, s) : 0.0f;
-            rel_v = axpy(cf, s, rel_v);
+            float vs = dot(rel_v, s);
+            float fk = ffma(-sl_damp[k], vs, tau_sl[k]);  // motor + MJCF joint damping of the slide dof
+            F = axpy(k < ns && is_joint ? fk : 0.0f, s, F);
+            rel_v = axpy(k < ns ? -vs : 0.0f, s, rel_v);
           }
         }
         T = axpy(-ang_damp, rel_w, T);
@@ -378,11 +382,36 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         const v3x2 P2 = bcast3(scale(d, g));
         const v3x2 lin = scale2(P2, mk2(-ip.inv_mass, ic.inv_mass));  // (dp_p, dc_p)
         v3x2 dth2 = scale2(iinv2<ISO>(ip, ic, R2, cross2(arm, P2)), mk2(-1.0f, 1.0f));  // (dp_th, dc_th)
-        // angular alignment by joint type (1 hinge: Xc || Xp; 2 hinges: Yc _|_ Xp; 3: free)
+        v3x2 lin2 = lin;
+        if constexpr (SLIDES) {  // slide limits: push the child back along the slide axis by the violation
+#pragma unroll
+          for (int k = 0; k < 3; ++k) {
+            v3 sx = rot(saxis[k], f.aprot);
+            float qs = dot(sub(f.ac, f.ap), sx);
+            float viol = qs < sl_lo[k] ? qs - sl_lo[k] : (qs > sl_hi[k] ? qs - sl_hi[k] : 0.0f);
+            viol = k < ns ? viol : 0.0f;
+            v3 dl = scale(sx, -viol);
+            float l2 = dot(dl, dl);
+            const v3x2 dl2 = bcast3(dl);
+            const v3x2 lcr = cross2(arm, dl2);
+            const f2 lw = dot2(lcr, iinv2<ISO>(ip, ic, R2, lcr));
+            float dens = ffma(invm_sum, l2, lw.x + lw.y);
+            float gs = (l2 / (dens + 1e-20f)) * js_pos;
+            const v3x2 Ps2 = bcast3(scale(dl, gs));
+            lin2 = add2(lin2, scale2(Ps2, mk2(-ip.inv_mass, ic.inv_mass)));
+            dth2 = add2(dth2, scale2(iinv2<ISO>(ip, ic, R2, cross2(arm, Ps2)), mk2(-1.0f, 1.0f)));
+          }
+        }
+        // angular alignment by joint type (0 hinges: weld; 1: Xc || Xp; 2: Yc _|_ Xp; 3: free)
         v3 A = sel3(nr == 1, f.Xc, f.Xp);
         v3 Bv = sel3(nr == 1, f.Xp, f.Yc);
         float sc = nr_eff == 1 ? 1.0f : (nr_eff == 2 ? dot(f.Xp, f.Yc) : 0.0f);
         v3 e = scale(cross(A, Bv), sc);
+        if constexpr (SLIDES) {  // joints without a hinge dof keep the child's orientation locked to the parent's
+          q4 qe = qmul(f.aprot, conj(f.acrot));
+          float sg = qe.w < 0.0f ? -2.0f : 2.0f;
+          e = sel3(nr_eff == 0, mk3(sg * qe.x, sg * qe.y, sg * qe.z), e);
+        }
         ang_correct<ISO>(e, ip, ic, R2, js_ang, dth2);
         auto limit = [&](int k, v3 ax, float a) {
           float viol = a < lim_lo[k] ? a - lim_lo[k] : (a > lim_hi[k] ? a - lim_hi[k] : 0.0f);
@@ -392,7 +421,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         limit(0, f.Xp, f.ang0);
         limit(1, f.ax1, f.ang1);
         limit(2, f.Zc, f.ang2);
-        dc_p = hi3(lin); dp_p = lo3(lin);
+        dc_p = hi3(lin2); dp_p = lo3(lin2);
         dc_th = hi3(dth2); dp_th = lo3(dth2);
       }
       {
@@ -488,6 +517,19 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
 
     // ---- reward (env wrapper's _get_reward) and tracked positions ------------------------------------
     const v3 o1 = sub(p, rot(com, r));
+    float cart_cos = 0.0f, cart_vs = 0.0f;
+    if (rkind == MBD_REW_CARTPOLE) {  // cartpole.py:45: cos(q[1]) - |qd[0]| (wave-uniform branch)
+      v3 Pp = shfl3(p, plane);
+      q4 Pr = shfl4(r, plane);
+      if (world_parent) { Pp = mk3(0, 0, 0); Pr = q4{1, 0, 0, 0}; }
+      JointFrames f = joint_frames(jc, Pp, Pr, p, r);
+      v3 sx = rot(saxis[0], f.aprot);
+      v3 vc = add(v, cross(w, sub(f.ac, p)));  // link 0 hangs off the static world
+      float sn, cs;
+      sincos_(f.ang0, &sn, &cs);
+      cart_vs = dot(vc, sx);                    // own slide-0 velocity: used on lane 0
+      cart_cos = shfl(cs, base + 1);            // cos of link 1's hinge angle, fetched by lane 0
+    }
     if (l_raw == 0) {
       float rew;
       if (rkind == MBD_REW_HUMANOIDRUN) {
@@ -496,6 +538,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         rew = o1.x - fclip(fabs_(o1.z - rp0), -1.0f, 1.0f) * rp1;
       } else if (rkind == MBD_REW_HALFCHEETAH) {
         rew = rp0 * ((o1.x - o0.x) / dt_ctrl) - rp1 * ctrl_cost;
+      } else if (rkind == MBD_REW_CARTPOLE) {
+        rew = cart_cos - fabs_(cart_vs);
       } else if (rkind == MBD_REW_HUMANOIDSTANDUP) {
         rew = 1.5f - fclip(fabs_(o1.z - 1.3f), -2.0f, 1.0f) - fabs_(o1.x) * 0.1f - fabs_(o1.y) * 0.1f;
       } else {

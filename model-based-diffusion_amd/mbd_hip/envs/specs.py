@@ -16,6 +16,10 @@ SPECS = {
                      reward_params=(1.1, 0.5)),
     # mbd/envs/humanoidstandup.py:14-27,50-56: the humanoid lying on the floor, 15 sphere colliders
     "humanoidstandup": dict(xml="humanoidstandup.xml", from_reference=True, n_frames=7, reset_noise=0.01),
+    # mbd/envs/cartpole.py:11-37,45: the reference's own 2-link model; positional backend -> dt 0.005, n_frames 4;
+    # reset adds [0, pi] to q (pole hanging down)
+    "cartpole": dict(xml="cartpole.xml", from_reference=True, n_frames=4, reset_noise=0.01, dt_override=0.005,
+                     init_q_offset=(0.0, 3.141592653589793)),
     # brax.envs.half_cheetah (absent): n_frames 16 @ 0.003125 s, reset noise 0.1, forward_reward_weight 1,
     # ctrl_cost_weight 0.1 — recollection, unpinned
     "halfcheetah": dict(xml="halfcheetah.xml", from_reference=False, n_frames=16, reset_noise=0.1,
@@ -23,4 +27,4 @@ SPECS = {
 }
 
 # names mbd.envs.get_env knows (mbd/envs/__init__.py:13-33) that are outside the hot-path scope
-OUT_OF_SCOPE = ("pushT", "cartpole", "ant")
+OUT_OF_SCOPE = ("pushT", "ant")

@@ -232,7 +232,8 @@ def _fuse(b: _Body) -> None:
 
 def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Optional[str] = None,
          track_names: Sequence[str] = (), reset_noise: float = 0.0,
-         reward_params: Sequence[float] = ()) -> Model:
+         reward_params: Sequence[float] = (), dt_override: Optional[float] = None,
+         init_q_offset: Sequence[float] = ()) -> Model:
     """Compile an MJCF file. ``n_frames`` is the env's physics substeps per control step
     (humanoidrun.py:17 -> 7, humanoidtrack.py:46 -> 5, hopper.py:18 -> 20)."""
     root = ET.parse(path).getroot()
@@ -247,6 +248,8 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
             defaults[ch.tag] = dict(ch.attrib)
     opt = root.find("option")
     dt = float(opt.get("timestep", 0.002)) if opt is not None else 0.002
+    if dt_override is not None:  # e.g. cartpole.py:18 sys.replace(dt=0.005)
+        dt = float(dt_override)
     gravity = _floats(opt.get("gravity") if opt is not None else None, 3, np.array([0, 0, -9.81]))
     custom = dict(_CUSTOM_DEFAULTS)
     cst = root.find("custom")
@@ -291,12 +294,15 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
              inv_inertia=z(L, 6), com=z(L, 3), ap_pos=z(L, 3), ap_rot=z(L, 4), ac_pos=z(L, 3),
              ac_rot=z(L, 4), ang_damp=z(L), vel_damp=z(L), rot_lo=z(L, 3), rot_hi=z(L, 3),
              rot_stiff=z(L, 3), rot_damp=z(L, 3), rot_sign=z(L, 3), slide_axis=z(L, 3, 3),
+             slide_lo=z(L, 3), slide_hi=z(L, 3), slide_damp=z(L, 3),
              link_pos=z(L, 3), link_rot=z(L, 4), joint_pos=z(L, 3), rot_axis=z(L, 3, 3),
              slide_axis_body=z(L, 3, 3))
     F["ap_rot"][:, 0] = 1
     F["ac_rot"][:, 0] = 1
     F["link_rot"][:, 0] = 1
     F["rot_sign"][:] = 1
+    F["slide_lo"][:] = -_BIG
+    F["slide_hi"][:] = _BIG
     init_q: List[float] = []
     joint_slot: Dict[str, tuple] = {}
     com64 = np.zeros((L, 3))
@@ -400,6 +406,12 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
             a = a / np.linalg.norm(a)
             F["slide_axis_body"][l, k] = a
             F["slide_axis"][l, k] = Rj.T @ a
+            limited = j.get("limited")
+            if (limited == "true" or (limited not in ("true", "false") and "range" in j)) and "range" in j:
+                F["slide_lo"][l, k], F["slide_hi"][l, k] = _floats(j["range"], 2)
+            F["slide_damp"][l, k] = float(j.get("damping", 0.0))
+            if float(j.get("stiffness", 0.0)) != 0.0:
+                raise ValueError(f"body {b.name!r}: slide joint stiffness is outside the hot-path subset")
             joint_slot[j.get("name", f"{b.name}_s{k}")] = (l, 3 + k, 1.0)
         p = ent["parent"]
         pcom = com64[p] if p >= 0 else np.zeros(3)
@@ -442,6 +454,8 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
             act_lo.append(lo); act_hi.append(hi); act_names.append(a.get("name", a["joint"]))
     if len(act_link) > MAX_ACT:
         raise ValueError("too many actuators")
+    for k, off in enumerate(init_q_offset):
+        init_q[k] += float(off)
     names = [ent["body"].name for ent in links]
     track = [names.index(n) for n in track_names]
     if len(track) > MAX_TRACK:

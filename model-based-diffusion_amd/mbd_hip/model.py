@@ -20,7 +20,7 @@ MAX_TRACK = 8
 LINK_STATE = 13
 
 REWARD_KINDS = {"humanoidrun": 0, "hopper": 1, "halfcheetah": 2, "humanoidtrack": 3, "walker2d": 1,
-                "humanoidstandup": 4}
+                "humanoidstandup": 4, "cartpole": 5}
 
 _L, _A, _K, _T = MAX_LINKS, MAX_ACT, MAX_COL, MAX_TRACK
 _f, _i = C.c_float, C.c_int32
@@ -44,6 +44,7 @@ class MbdModel(C.Structure):
         ("rot_lo", (_f * 3) * _L), ("rot_hi", (_f * 3) * _L), ("rot_stiff", (_f * 3) * _L),
         ("rot_damp", (_f * 3) * _L), ("rot_sign", (_f * 3) * _L),
         ("slide_axis", ((_f * 3) * 3) * _L),
+        ("slide_lo", (_f * 3) * _L), ("slide_hi", (_f * 3) * _L), ("slide_damp", (_f * 3) * _L),
         ("act_link", _i * _A), ("act_slot", _i * _A), ("act_gear", _f * _A), ("act_lo", _f * _A),
         ("act_hi", _f * _A),
         ("col_link", _i * _K), ("col_pos", (_f * 3) * _K), ("col_radius", _f * _K),
@@ -96,6 +97,8 @@ class Model:
             ctype_arr = getattr(s, name)
             dst = np.ctypeslib.as_array(ctype_arr)
             src = np.asarray(self.fields[name])
+            if src.size == 0:
+                continue
             view = dst[tuple(slice(0, n) for n in src.shape)] if src.ndim else dst
             view[...] = src
         return s

@@ -174,8 +174,9 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     for (int k = 0; k < m->n_slide[l]; ++k) {
       real s[3], sa[3] = {m->slide_axis[l][k][0], m->slide_axis[l][k][1], m->slide_axis[l][k][2]};
       sp_rot(sa, f.aprot, s);
-      sp_axpy3(tau_slide[l * 3 + k], s, F);
-      sp_axpy3(-sp_dot3(rel_v, s), s, rel_v); /* free direction: not damped */
+      real vs = sp_dot3(rel_v, s);
+      sp_axpy3(sp_fma(-R(m->slide_damp[l][k]), vs, tau_slide[l * 3 + k]), s, F); /* motor + MJCF joint damping */
+      sp_axpy3(-vs, s, rel_v); /* free direction: no constraint damping */
     }
     sp_axpy3(-R(m->ang_damp[l]), rel_w, T);
     sp_axpy3(-R(m->vel_damp[l]), rel_v, F);
@@ -238,6 +239,30 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_cross3(rc, Pimp, mom); iinv_apply(ic, mom, dc_th[l]);
     sp_scale3(Pimp, -ip->inv_mass, dp_p[l]);
     sp_cross3(rp, Pimp, mom); iinv_apply(ip, mom, t); sp_scale3(t, R(-1), dp_th[l]);
+    /* slide limits: push the child back along the slide axis by the violation (same one-division form) */
+    for (int k = 0; k < m->n_slide[l]; ++k) {
+      real sx[3], sa[3] = {m->slide_axis[l][k][0], m->slide_axis[l][k][1], m->slide_axis[l][k][2]};
+      sp_rot(sa, f.aprot, sx);
+      real apc[3];
+      sp_sub3(f.ac, f.ap, apc);
+      real qs = sp_dot3(apc, sx);
+      real lo = R(m->slide_lo[l][k]), hi = R(m->slide_hi[l][k]);
+      real viol = qs < lo ? qs - lo : (qs > hi ? qs - hi : R(0));
+      real dl[3];
+      sp_scale3(sx, -viol, dl);
+      real l2 = sp_dot3(dl, dl);
+      real lp[3], lc[3], ilp[3], ilc[3];
+      sp_cross3(rp, dl, lp); sp_cross3(rc, dl, lc);
+      iinv_apply(ip, lp, ilp); iinv_apply(ic, lc, ilc);
+      real dens = sp_fma(ip->inv_mass + ic->inv_mass, l2, sp_dot3(lp, ilp) + sp_dot3(lc, ilc));
+      real gs = (l2 / (dens + R(1e-20))) * R(m->joint_scale_pos);
+      real Ps[3], u[3];
+      sp_scale3(dl, gs, Ps);
+      sp_scale3(Ps, ic->inv_mass, u); sp_add3(dc_p[l], u, dc_p[l]);
+      sp_cross3(rc, Ps, mom); iinv_apply(ic, mom, u); sp_add3(dc_th[l], u, dc_th[l]);
+      sp_scale3(Ps, -ip->inv_mass, u); sp_add3(dp_p[l], u, dp_p[l]);
+      sp_cross3(rp, Ps, mom); iinv_apply(ip, mom, u); sp_scale3(u, R(-1), u); sp_add3(dp_th[l], u, dp_th[l]);
+    }
     /* angular alignment by joint type */
     real e[3] = {0, 0, 0};
     const int nr = m->n_rot[l];
@@ -420,6 +445,19 @@ static real env_step(const mbd_model_t* m, xf_t* x, mo_t* xd, const float* actio
     }
     case MBD_REW_HUMANOIDTRACK: /* humanoidtrack.py:87-96: from the INCOMING state */
       return R(1) + (-sp_abs(v0[0] - R(1.6)) - sp_abs(o0[2] - R(1.3)) - sp_abs(o0[1]) * R(0.1));
+    case MBD_REW_CARTPOLE: { /* cartpole.py:45: cos(q[1]) - |qd[0]|: hinge angle of link 1, slide velocity of link 0 */
+      static const xf_t WORLD_X = {{0, 0, 0}, {1, 0, 0, 0}};
+      jf_t f0, f1;
+      joint_frames(m, 0, &WORLD_X, &x[0], &f0);
+      joint_frames(m, 1, &x[0], &x[1], &f1);
+      real sx[3], sa[3] = {m->slide_axis[0][0][0], m->slide_axis[0][0][1], m->slide_axis[0][0][2]}, rc0[3], t[3], vc[3];
+      sp_rot(sa, f0.aprot, sx);
+      sp_sub3(f0.ac, x[0].p, rc0);
+      sp_cross3(xd[0].w, rc0, t); sp_add3(xd[0].v, t, vc); /* the parent is the static world */
+      real sn, cs;
+      sp_sincos(f1.ang[0], &sn, &cs);
+      return cs - sp_abs(sp_dot3(vc, sx));
+    }
     case MBD_REW_HUMANOIDSTANDUP: /* humanoidstandup.py:50-56 */
       return R(1.5) - sp_clip(sp_abs(o1[2] - R(1.3)), R(-2), R(1)) - sp_abs(o1[0]) * R(0.1) - sp_abs(o1[1]) * R(0.1);
     default: return 0;

@@ -118,7 +118,7 @@ def test_humanoid_zero_action_feet_rest_on_floor(orc):
 
 
 @pytest.mark.parametrize("name", ["humanoidrun", "humanoidtrack", "hopper", "halfcheetah", "walker2d",
-                                  "humanoidstandup"])
+                                  "humanoidstandup", "cartpole"])
 def test_rollouts_stay_finite_and_actions_saturate(orc, name):
     m = load_model(name)
     ms = m.to_struct()
@@ -162,3 +162,25 @@ def test_chaos_amplification(orc, orc64):
     err = np.abs(r32 - r64)
     assert err[:, 0].max() < 5e-6            # one control step: round-off only
     assert err[:, -1].max() > 1e-4           # 350 substeps later: amplified by orders of magnitude
+
+
+def test_cartpole_weld_limits_and_reward(orc):
+    """The reference's own 2-link model (mbd/assets/cartpole.xml, mbd/envs/cartpole.py): the slide-only cart keeps
+    its orientation (weld alignment), respects the +-1 m rail limit, and the reward is cos(q1) - |qd0|."""
+    m = load_model("cartpole")
+    ms = m.to_struct()
+    assert m.fields["n_rot"].tolist() == [0, 1] and m.fields["n_slide"].tolist() == [1, 0]
+    assert np.allclose(m.init_q, [0.0, np.pi]) and abs(m.fields["dt"] - 0.005) < 1e-9 and m.fields["n_frames"] == 4
+    st = orc.forward(ms, m.init_q, np.zeros(2, np.float32))
+    st, r = orc.env_step(ms, st, np.zeros(1, np.float32))
+    assert abs(r - (-1.0)) < 1e-3                      # pole hanging down, cart at rest
+    push = np.array([3.0], np.float32)                 # ctrlrange +-3, gear 100
+    xs = []
+    for _ in range(150):
+        st, r = orc.env_step(ms, st, push)
+        xs.append(st[0, 0])
+        ang = orc.joint_angles(ms, st)[1, 0]
+        assert abs(r - (np.cos(ang) - abs(st[0, 7]))) < 2e-3
+        assert np.allclose(st[0, 3:7], [1, 0, 0, 0], atol=2e-3)   # the cart does not rotate
+        assert abs(st[0, 1]) < 1e-3 and abs(st[0, 2]) < 8e-3      # and stays on its rail (soft PBD constraint)
+    assert max(xs) < 1.0 + 0.15 and max(xs) > 0.9                # pressed against the soft +1 m limit
