@@ -60,6 +60,9 @@ enum mbd_reward_kind {
   MBD_REW_HALFCHEETAH = 2,   /* brax.envs.half_cheetah (absent from the reference tree)              */
   MBD_REW_HUMANOIDTRACK = 3, /* mbd/envs/humanoidtrack.py:87-96 (computed from the INCOMING state)   */
   MBD_REW_HUMANOIDSTANDUP = 4, /* mbd/envs/humanoidstandup.py:50-56                                   */
+  MBD_REW_ANT = 6,           /* brax.envs.ant (absent): forward_reward + healthy_reward - ctrl_cost:
+                                p0*(x1-x0)/dt + (p2 <= z <= p3 ? p4 : 0) - p1*|a|^2, reward_params =
+                                (1, 0.5, 0.2, 1.0, 1.0) — recollection, unpinned                        */
   MBD_REW_CARTPOLE = 5       /* mbd/envs/cartpole.py:45: cos(q[1]) - |qd[0]| (hinge of link 1, slide of link 0) */
 };
 

@@ -372,7 +372,8 @@ extern "C" int mbd_env_reset(const mbd_env* e, const uint32_t key[2], int impl, 
       q[i] = m.init_q[i] + bits_to_uniform(random_bits32(keys[2], keys[3], impl, i, m.n_q), -s, s);
     for (int i = 0; i < m.n_qd; ++i) {
       uint32_t bits = random_bits32(keys[4], keys[5], impl, i, m.n_qd);
-      qd[i] = m.reward_kind == MBD_REW_HALFCHEETAH ? s * bits_to_normal(bits) : bits_to_uniform(bits, -s, s);
+      qd[i] = (m.reward_kind == MBD_REW_HALFCHEETAH || m.reward_kind == MBD_REW_ANT) ? s * bits_to_normal(bits)
+                                                                                  : bits_to_uniform(bits, -s, s);
     }
   }
   host_forward(m, q, qd, state_out);

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       tau_sl[k] = SLIDES ? fclip(act_sl[k] >= 0 ? u_sl[k] : 0.0f, alo_sl[k], ahi_sl[k]) * gear_sl[k] : 0.0f;
     }
     float ctrl_cost = 0.0f;
-    if (rkind == MBD_REW_HALFCHEETAH && l_raw == 0) {
+    if ((rkind == MBD_REW_HALFCHEETAH || rkind == MBD_REW_ANT) && l_raw == 0) {
       for (int a = 0; a < Nu; ++a) {
         float ua = u_row[(size_t)t * Nu + a];
         ctrl_cost = ctrl_cost + ua * ua;
@@ -538,6 +538,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         rew = o1.x - fclip(fabs_(o1.z - rp0), -1.0f, 1.0f) * rp1;
       } else if (rkind == MBD_REW_HALFCHEETAH) {
         rew = rp0 * ((o1.x - o0.x) / dt_ctrl) - rp1 * ctrl_cost;
+      } else if (rkind == MBD_REW_ANT) {
+        float healthy = (o1.z >= M->reward_params[2] && o1.z <= M->reward_params[3]) ? M->reward_params[4] : 0.0f;
+        rew = (rp0 * ((o1.x - o0.x) / dt_ctrl) + healthy) - rp1 * ctrl_cost;
       } else if (rkind == MBD_REW_CARTPOLE) {
         rew = cart_cos - fabs_(cart_vs);
       } else if (rkind == MBD_REW_HUMANOIDSTANDUP) {

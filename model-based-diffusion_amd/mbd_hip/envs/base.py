@@ -236,6 +236,8 @@ class RigidBodyEnv(_EnvBase):
             pos = q.copy()
             pos[1] = self.link_positions(pipeline_state)[0, 2]
             return np.concatenate([pos, np.clip(qd, -10, 10)]).astype(np.float32)
+        if self.env_name == "ant":  # brax ant: root x, y excluded
+            return np.concatenate([q[2:], qd]).astype(np.float32)
         if self.env_name == "halfcheetah":  # brax half_cheetah: the root x position is excluded
             return np.concatenate([q[1:], qd]).astype(np.float32)
         return np.concatenate([q, qd]).astype(np.float32)  # humanoidrun.py:43-44 etc.
@@ -251,7 +253,7 @@ class RigidBodyEnv(_EnvBase):
     @property
     def observation_size(self) -> int:
         n = self.sys.q_size() + self.sys.qd_size()
-        return n - 1 if self.env_name == "halfcheetah" else n
+        return n - {"halfcheetah": 1, "ant": 2}.get(self.env_name, 0)
 
     def link_positions(self, pipeline_state) -> np.ndarray:
         """x.pos of every link (world position of the link-frame origin) from a [L,13] state."""

@@ -20,6 +20,11 @@ SPECS = {
     # reset adds [0, pi] to q (pole hanging down)
     "cartpole": dict(xml="cartpole.xml", from_reference=True, n_frames=4, reset_noise=0.01, dt_override=0.005,
                      init_q_offset=(0.0, 3.141592653589793)),
+    # brax.envs.ant (absent; selected by name at mbd/envs/__init__.py:30-31 and the DEFAULT env_name of Args,
+    # mbd_planner.py:25): positional backend dt 0.005, n_frames 10, reset noise 0.1 (uniform q, normal qd),
+    # reward = forward velocity + healthy(1.0 while 0.2 <= z <= 1.0) - 0.5 |a|^2 — recollection, unpinned
+    "ant": dict(xml="ant.xml", from_reference=False, n_frames=10, reset_noise=0.1,
+                reward_params=(1.0, 0.5, 0.2, 1.0, 1.0)),
     # brax.envs.half_cheetah (absent): n_frames 16 @ 0.003125 s, reset noise 0.1, forward_reward_weight 1,
     # ctrl_cost_weight 0.1 — recollection, unpinned
     "halfcheetah": dict(xml="halfcheetah.xml", from_reference=False, n_frames=16, reset_noise=0.1,
@@ -27,4 +32,4 @@ SPECS = {
 }
 
 # names mbd.envs.get_env knows (mbd/envs/__init__.py:13-33) that are outside the hot-path scope
-OUT_OF_SCOPE = ("pushT", "ant")
+OUT_OF_SCOPE = ("pushT",)

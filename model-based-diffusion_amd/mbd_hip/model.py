@@ -20,7 +20,7 @@ MAX_TRACK = 8
 LINK_STATE = 13
 
 REWARD_KINDS = {"humanoidrun": 0, "hopper": 1, "halfcheetah": 2, "humanoidtrack": 3, "walker2d": 1,
-                "humanoidstandup": 4, "cartpole": 5}
+                "humanoidstandup": 4, "cartpole": 5, "ant": 6}
 
 _L, _A, _K, _T = MAX_LINKS, MAX_ACT, MAX_COL, MAX_TRACK
 _f, _i = C.c_float, C.c_int32

@@ -445,6 +445,13 @@ static real env_step(const mbd_model_t* m, xf_t* x, mo_t* xd, const float* actio
     }
     case MBD_REW_HUMANOIDTRACK: /* humanoidtrack.py:87-96: from the INCOMING state */
       return R(1) + (-sp_abs(v0[0] - R(1.6)) - sp_abs(o0[2] - R(1.3)) - sp_abs(o0[1]) * R(0.1));
+    case MBD_REW_ANT: { /* brax ant: forward velocity + healthy bonus - ctrl cost */
+      real ctrl = 0;
+      for (int a = 0; a < m->n_act; ++a) ctrl += R(action[a]) * R(action[a]);
+      real dtc = R(m->dt) * (real)m->n_frames;
+      real healthy = (o1[2] >= R(m->reward_params[2]) && o1[2] <= R(m->reward_params[3])) ? R(m->reward_params[4]) : R(0);
+      return (R(m->reward_params[0]) * ((o1[0] - o0[0]) / dtc) + healthy) - R(m->reward_params[1]) * ctrl;
+    }
     case MBD_REW_CARTPOLE: { /* cartpole.py:45: cos(q[1]) - |qd[0]|: hinge angle of link 1, slide velocity of link 0 */
       static const xf_t WORLD_X = {{0, 0, 0}, {1, 0, 0, 0}};
       jf_t f0, f1;

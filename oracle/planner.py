@@ -27,7 +27,7 @@ class OracleEnv:
         if s > 0:  # humanoidrun.py:21-27, hopper.py:22-28, walker2d.py:21-27, humanoidstandup.py:21-27
             keys = self.orc.split(key, 3, impl)
             q = (q + self.orc.uniform(keys[1], m.n_q, -s, s, impl)).astype(np.float32)
-            if self.name == "halfcheetah":
+            if self.name in ("halfcheetah", "ant"):  # brax: qvel = hi * normal(rng2)
                 qd = (s * self.orc.normal(keys[2], (m.n_qd,), impl)).astype(np.float32)
             else:
                 qd = self.orc.uniform(keys[2], m.n_qd, -s, s, impl)

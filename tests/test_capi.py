@@ -66,7 +66,7 @@ def test_get_env_errors_like_the_reference(lib):
     with pytest.raises(ValueError, match="Unknown environment"):
         get_env("no_such_env")
     with pytest.raises(ValueError):
-        get_env("pushT")  # in the reference registry, outside the hot-path scope
+        get_env("pushT")  # in the reference registry (generalized backend), outside the hot-path scope
     if _capi.device_count() == 0:
         # no GPU here: the product must fail loudly, never fall back to a CPU path
         with pytest.raises(_capi.MbdError) as e:

@@ -46,7 +46,7 @@ def test_prng_split_and_reset(gpu, orc, impl, monkeypatch):
     for num in (2, 3):
         assert np.array_equal(gpu.prng_split(key, num, impl), orc.split(key, num, impl))
     for name in ("humanoidrun", "hopper", "halfcheetah", "humanoidtrack", "walker2d", "humanoidstandup",
-                 "cartpole", "car2d"):
+                 "cartpole", "ant", "car2d"):
         env = get_env(name)
         st = env.reset(key)
         ref = _oenv(orc, env).reset(key, impl)
@@ -57,7 +57,7 @@ def test_prng_split_and_reset(gpu, orc, impl, monkeypatch):
                                             ("humanoidtrack", 64, 50, 0.4), ("hopper", 80, 50, 0.5),
                                             ("halfcheetah", 72, 50, 0.5), ("walker2d", 40, 50, 0.5),
                                             ("humanoidstandup", 36, 50, 0.5), ("cartpole", 200, 50, 0.8),
-                                            ("car2d", 128, 30, 0.5),
+                                            ("ant", 44, 50, 0.5), ("car2d", 128, 30, 0.5),
                                             ("car2d", 3, 50, 1.0)])
 def test_rollout_bitexact(gpu, orc, name, B, H, sigma):
     from mbd_hip.envs import get_env
@@ -147,6 +147,7 @@ def test_reverse_once_walker2d_and_standup(gpu, orc):
     _one_step(gpu, orc, "walker2d", 128, 50, 100, 0.1, 1, False, i=60)
     _one_step(gpu, orc, "humanoidstandup", 96, 50, 100, 0.1, 1, False, i=90)
     _one_step(gpu, orc, "cartpole", 256, 50, 100, 0.1, 1, False, i=95)
+    _one_step(gpu, orc, "ant", 128, 50, 100, 0.1, 1, False, i=70)
 
 
 def test_reverse_once_halfcheetah(gpu, orc):

@@ -118,7 +118,7 @@ def test_humanoid_zero_action_feet_rest_on_floor(orc):
 
 
 @pytest.mark.parametrize("name", ["humanoidrun", "humanoidtrack", "hopper", "halfcheetah", "walker2d",
-                                  "humanoidstandup", "cartpole"])
+                                  "humanoidstandup", "cartpole", "ant"])
 def test_rollouts_stay_finite_and_actions_saturate(orc, name):
     m = load_model(name)
     ms = m.to_struct()

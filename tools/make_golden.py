@@ -15,7 +15,7 @@ CASES = [("car2d", 0, 32, 30, 50, 0.1, 1, 6), ("humanoidrun", 0, 16, 12, 20, 0.1
          ("humanoidrun", 1, 16, 12, 20, 0.1, 0, 3), ("hopper", 0, 16, 12, 20, 0.1, 1, 3),
          ("halfcheetah", 0, 16, 12, 20, 0.4, 1, 3), ("humanoidtrack", 0, 16, 12, 20, 0.1, 1, 3),
          ("walker2d", 0, 16, 12, 20, 0.1, 1, 3), ("humanoidstandup", 0, 16, 12, 20, 0.1, 1, 3),
-         ("cartpole", 0, 16, 12, 20, 0.1, 1, 3)]
+         ("cartpole", 0, 16, 12, 20, 0.1, 1, 3), ("ant", 0, 16, 12, 20, 0.1, 1, 3)]
 
 
 def main():
