@@ -363,3 +363,12 @@ def test_render_outputs_mu0ts_and_replay(gpu, tmp_path, monkeypatch):
     for r in rs["rewards"]:
         s = np.float32(s + r)
     assert np.float32(s / np.float32(20)) == np.float32(rew)   # step-by-step replay == rollout kernel
+
+
+def test_metric_config_full_size_step_bitexact(gpu):
+    """The BASELINE metric configuration at FULL size (humanoidrun, N=1024, H=50, Ndiffuse=100): two
+    consecutive reverse-diffusion steps, bit for bit against the oracle (OpenMP build: ~1 s on the GPU box)."""
+    from oracle import oracle as orc_mod
+    orc_mod.build()
+    _one_step(gpu, orc_mod.Oracle("f32_omp"), "humanoidrun", 1024, 50, 100, 0.1, 1, False, i=99)
+    _one_step(gpu, orc_mod.Oracle("f32_omp"), "humanoidrun", 1024, 50, 100, 0.1, 1, False, i=3)
