@@ -42,8 +42,8 @@ def main():
         if m and m.group(1) in lab and lab[m.group(1)] < k:
             ins = [x.strip().split()[0] for x in body[lab[m.group(1)]:k + 1]
                    if x.startswith("\t") and not x.strip().startswith((".", ";"))]
-            nb = sum(1 for i in ins if i == "ds_bpermute_b32")
-            if nb >= 40 and (best is None or len(ins) < len(best)):
+            nb = sum(1 for i in ins if i.startswith("ds_"))
+            if nb >= 20 and (best is None or len(ins) < len(best)):
                 best = ins
     c = collections.Counter(best)
     flops = 0
@@ -57,7 +57,7 @@ def main():
         elif k.startswith(("v_mul_f32", "v_add_f32", "v_sub_f32", "v_rcp_f32", "v_sqrt_f32", "v_div_")):
             flops += v
     res = {"instructions_per_substep": len(best), "valu_per_substep": sum(v for k, v in c.items() if k.startswith("v_")),
-           "ds_bpermute_per_substep": c["ds_bpermute_b32"], "fp32_flops_per_lane_substep": flops}
+           "lds_instr_per_substep": sum(v for k, v in c.items() if k.startswith("ds_")), "fp32_flops_per_lane_substep": flops}
     print(json.dumps(res))
     if "--write" in sys.argv:
         with open(os.path.join(ROOT, "profiles", "r01_static_flops.json"), "w") as f:
