@@ -36,15 +36,17 @@ def main():
         m = re.match(r"^(\.LBB\d+_\d+):", l)
         if m:
             lab[m.group(1)] = k
-    best = None
+    loops = []
     for k, l in enumerate(body):
         m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
         if m and m.group(1) in lab and lab[m.group(1)] < k:
             ins = [x.strip().split()[0] for x in body[lab[m.group(1)]:k + 1]
                    if x.startswith("\t") and not x.strip().startswith((".", ";"))]
-            nb = sum(1 for i in ins if i.startswith("ds_"))
-            if nb >= 20 and (best is None or len(ins) < len(best)):
-                best = ins
+            loops.append((sum(1 for i in ins if i.startswith("ds_")), ins))
+    # the substep loop = the smallest loop that contains ALL of the kernel's in-loop LDS exchange
+    # instructions (the control-step loop around it contains them too, but is longer)
+    most = max(n for n, _ in loops)
+    best = min((ins for n, ins in loops if n == most), key=len)
     c = collections.Counter(best)
     flops = 0
     for k, v in c.items():
