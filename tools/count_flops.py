@@ -43,10 +43,9 @@ def main():
             ins = [x.strip().split()[0] for x in body[lab[m.group(1)]:k + 1]
                    if x.startswith("\t") and not x.strip().startswith((".", ";"))]
             loops.append((sum(1 for i in ins if i.startswith("ds_")), ins))
-    # the substep loop = the smallest loop that contains ALL of the kernel's in-loop LDS exchange
-    # instructions (the control-step loop around it contains them too, but is longer)
-    most = max(n for n, _ in loops)
-    best = min((ins for n, ins in loops if n == most), key=len)
+    # the substep loop = the smallest loop holding the 56 ds_bpermute of one substep (13 + 18 + 7 + 18); the
+    # control-step loop around it holds them too (plus the cartpole reward's), but is longer
+    best = min((ins for n, ins in loops if n >= 56), key=len)
     c = collections.Counter(best)
     flops = 0
     for k, v in c.items():
