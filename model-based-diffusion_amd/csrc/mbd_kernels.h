@@ -93,7 +93,7 @@ __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp,
   float sb = fclip(dot(C.Z, A.X), -1.0f, 1.0f);
   float cb2 = ffma(-sb, sb, 1.0f);
   float cb = fsqrt(cb2 < 0.0f ? 0.0f : cb2);
-  float inv = 1.0f / (cb + 1e-10f);
+  float inv = div_(1.0f, cb + 1e-10f);
   const f2 a02 = angle_unit2(mk2(-dot(C.Z, A.Y) * inv, -dot(C.Y, A.X) * inv),
                              mk2(dot(C.Z, A.Z) * inv, dot(C.X, A.X) * inv));
   f.ang0 = a02.x;
@@ -120,16 +120,25 @@ __device__ __forceinline__ v3x2 iinv2(const Inert<ISO>& ip, const Inert<ISO>& ic
   }
 }
 // one angular positional correction (rotate child by +e, parent by -e): I^-1 e * |e|^2 /
-// (e.I_p^-1 e + e.I_c^-1 e) — one division, no square root. dth2 = (dth_p, dth_c) packed.
+// (e.I_p^-1 e + e.I_c^-1 e) — one division, no square root.  Split in two so that independent corrections
+// share a packed division: prepare -> (I^-1 e pair, numerator, denominator); the caller divides; apply.
+struct AngPrep {
+  v3x2 in2;  // (I_p^-1 e, I_c^-1 e)
+  float num, den;
+};
 template <bool ISO>
-__device__ __forceinline__ void ang_correct(v3 e, const Inert<ISO>& ip, const Inert<ISO>& ic, q4x2 R2, float sc,
-                                            v3x2& dth2) {
+__device__ __forceinline__ AngPrep ang_prepare(v3 e, const Inert<ISO>& ip, const Inert<ISO>& ic, q4x2 R2) {
+  AngPrep a;
   v3x2 e2 = bcast3(e);
-  v3x2 in2 = iinv2<ISO>(ip, ic, R2, e2);  // (I_p^-1 e, I_c^-1 e)
-  f2 d2 = dot2(e2, in2);
-  float den = d2.x + d2.y;
-  float g = (dot(e, e) / (den + 1e-20f)) * sc;
-  dth2 = axpy2(mk2(-g, g), in2, dth2);
+  a.in2 = iinv2<ISO>(ip, ic, R2, e2);
+  f2 d2 = dot2(e2, a.in2);
+  a.den = (d2.x + d2.y) + 1e-20f;
+  a.num = dot(e, e);
+  return a;
+}
+__device__ __forceinline__ void ang_apply(const AngPrep& a, float quot, float sc, v3x2& dth2) {
+  float g = quot * sc;
+  dth2 = axpy2(mk2(-g, g), a.in2, dth2);
 }
 // contact normal = +z of the floor plane
 __device__ __forceinline__ v3 crossz(v3 a) { return v3{a.y, -a.x, 0.0f}; }
@@ -377,8 +386,20 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         const v3x2 d2 = bcast3(d);
         const v3x2 cr = cross2(arm, d2);                       // (rp x d, rc x d)
         const f2 wq = dot2(cr, iinv2<ISO>(ip, ic, R2, cr));
-        float den = ffma(invm_sum, c2, wq.x + wq.y);
-        float g = (c2 / (den + 1e-20f)) * js_pos;
+        float den = ffma(invm_sum, c2, wq.x + wq.y) + 1e-20f;
+        // angular alignment by joint type (0 hinges: weld; 1: Xc || Xp; 2: Yc _|_ Xp; 3: free)
+        v3 A = sel3(nr == 1, f.Xc, f.Xp);
+        v3 Bv = sel3(nr == 1, f.Xp, f.Yc);
+        float sc = nr_eff == 1 ? 1.0f : (nr_eff == 2 ? dot(f.Xp, f.Yc) : 0.0f);
+        v3 e = scale(cross(A, Bv), sc);
+        if constexpr (SLIDES) {  // joints without a hinge dof keep the child's orientation locked to the parent's
+          q4 qe = qmul(f.aprot, conj(f.acrot));
+          float sg = qe.w < 0.0f ? -2.0f : 2.0f;
+          e = sel3(nr_eff == 0, mk3(sg * qe.x, sg * qe.y, sg * qe.z), e);
+        }
+        const AngPrep ca = ang_prepare<ISO>(e, ip, ic, R2);
+        const f2 q_ta = div2_(mk2(c2, ca.num), mk2(den, ca.den));  // translation and alignment quotients
+        float g = q_ta.x * js_pos;
         const v3x2 P2 = bcast3(scale(d, g));
         const v3x2 lin = scale2(P2, mk2(-ip.inv_mass, ic.inv_mass));  // (dp_p, dc_p)
         v3x2 dth2 = scale2(iinv2<ISO>(ip, ic, R2, cross2(arm, P2)), mk2(-1.0f, 1.0f));  // (dp_th, dc_th)
@@ -396,31 +417,26 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
             const v3x2 lcr = cross2(arm, dl2);
             const f2 lw = dot2(lcr, iinv2<ISO>(ip, ic, R2, lcr));
             float dens = ffma(invm_sum, l2, lw.x + lw.y);
-            float gs = (l2 / (dens + 1e-20f)) * js_pos;
+            float gs = div_(l2, dens + 1e-20f) * js_pos;
             const v3x2 Ps2 = bcast3(scale(dl, gs));
             lin2 = add2(lin2, scale2(Ps2, mk2(-ip.inv_mass, ic.inv_mass)));
             dth2 = add2(dth2, scale2(iinv2<ISO>(ip, ic, R2, cross2(arm, Ps2)), mk2(-1.0f, 1.0f)));
           }
         }
-        // angular alignment by joint type (0 hinges: weld; 1: Xc || Xp; 2: Yc _|_ Xp; 3: free)
-        v3 A = sel3(nr == 1, f.Xc, f.Xp);
-        v3 Bv = sel3(nr == 1, f.Xp, f.Yc);
-        float sc = nr_eff == 1 ? 1.0f : (nr_eff == 2 ? dot(f.Xp, f.Yc) : 0.0f);
-        v3 e = scale(cross(A, Bv), sc);
-        if constexpr (SLIDES) {  // joints without a hinge dof keep the child's orientation locked to the parent's
-          q4 qe = qmul(f.aprot, conj(f.acrot));
-          float sg = qe.w < 0.0f ? -2.0f : 2.0f;
-          e = sel3(nr_eff == 0, mk3(sg * qe.x, sg * qe.y, sg * qe.z), e);
-        }
-        ang_correct<ISO>(e, ip, ic, R2, js_ang, dth2);
-        auto limit = [&](int k, v3 ax, float a) {
+        ang_apply(ca, q_ta.y, js_ang, dth2);
+        // joint limits on the Euler angles: three corrections, quotients (0,1) packed, 2 alone
+        auto viol_of = [&](int k, float a) {
           float viol = a < lim_lo[k] ? a - lim_lo[k] : (a > lim_hi[k] ? a - lim_hi[k] : 0.0f);
-          viol = k < nr_eff ? viol : 0.0f;
-          ang_correct<ISO>(scale(ax, -viol), ip, ic, R2, js_ang, dth2);
+          return k < nr_eff ? viol : 0.0f;
         };
-        limit(0, f.Xp, f.ang0);
-        limit(1, f.ax1, f.ang1);
-        limit(2, f.Zc, f.ang2);
+        const AngPrep c0 = ang_prepare<ISO>(scale(f.Xp, -viol_of(0, f.ang0)), ip, ic, R2);
+        const AngPrep c1 = ang_prepare<ISO>(scale(f.ax1, -viol_of(1, f.ang1)), ip, ic, R2);
+        const AngPrep c2_ = ang_prepare<ISO>(scale(f.Zc, -viol_of(2, f.ang2)), ip, ic, R2);
+        const f2 q01 = div2_(mk2(c0.num, c1.num), mk2(c0.den, c1.den));
+        const float q2 = div_(c2_.num, c2_.den);
+        ang_apply(c0, q01.x, js_ang, dth2);
+        ang_apply(c1, q01.y, js_ang, dth2);
+        ang_apply(c2_, q2, js_ang, dth2);
         dc_p = hi3(lin2); dp_p = lo3(lin2);
         dc_th = hi3(dth2); dp_th = lo3(dth2);
       }
@@ -454,8 +470,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           v3 cn = crossz(rc);
           v3 icn = iinv<ISO>(ic, r, cn);
           float wn = ic.inv_mass + dot(cn, icn);
-          float dlam = (pen / wn) * coll_scale;
-          v3 Pimp = mk3(0.0f, 0.0f, dlam);
+          // (dlam and gt share one packed division below)
           v3 rl = irot(rc, r);
           v3 pprev = add(p_prev, rot(rl, r_prev));
           v3 dx = sub(pos, pprev);
@@ -464,7 +479,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           v3 cnt = cross(rc, dx);
           v3 icnt = iinv<ISO>(ic, r, cnt);
           float dent = ffma(ic.inv_mass, ct2, dot(cnt, icnt));
-          float gt = ct2 / (dent + 1e-20f);
+          const f2 q_ng = div2_(mk2(pen, ct2), mk2(wn, dent + 1e-20f));
+          float dlam = q_ng.x * coll_scale;
+          float gt = q_ng.y;
+          v3 Pimp = mk3(0.0f, 0.0f, dlam);
           float lim = mu * dlam;
           Pimp = sel3((ct2 * gt) * gt < lim * lim, axpy(-gt, dx, Pimp), Pimp);
           v3 ncd_p = axpy(ic.inv_mass, Pimp, cd_p);
@@ -496,7 +514,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         float vn = vpt.z;
         v3 vt = mk3(vpt.x, vpt.y, 0.0f);
         float vtn = fsqrt(ffma(vt.x, vt.x, vt.y * vt.y));
-        float inv = 1.0f / (vtn + 1e-10f);
+        float inv = div_(1.0f, vtn + 1e-10f);
         v3 dir = scale(vt, inv);
         v3 cn = crossz(rc), cdv = cross(rc, dir);
         v3 icn = iinv<ISO>(ic, r, cn), icd = iinv<ISO>(ic, r, cdv);
@@ -505,7 +523,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         float dvn = fmin_(rest, 0.0f) - vn;
         float jt_max = (mu * con_dlam[j]) * inv_dt;
         float dvt = fmin_(jt_max * wt, vtn);
-        float jn = dvn / wn, jt = -(dvt / wt);
+        const f2 q_nt = div2_(mk2(dvn, dvt), mk2(wn, wt));
+        float jn = q_nt.x, jt = -q_nt.y;
         v3 Pimp = scale(dir, jt);
         Pimp.z = Pimp.z + jn;
         v3 nv = axpy(ic.inv_mass, Pimp, v);

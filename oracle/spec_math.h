@@ -37,6 +37,11 @@ static inline real sp_min(real a, real b) { return a < b ? a : b; }
 static inline real sp_max(real a, real b) { return a > b ? a : b; }
 static inline real sp_clip(real v, real lo, real hi) { return v < lo ? lo : (v > hi ? hi : v); }
 
+/* the solver's division: numerators below 1e-28 in magnitude are flushed to zero (physically nothing; it keeps
+ * every quotient and residual a normal number, which is what lets the GPU use the bare reciprocal/FMA
+ * refinement sequence and still round exactly like this IEEE division — tools/probes/probe_div.hip) */
+static inline real sp_div(real n, real d) { return (sp_abs(n) < R(1e-28) ? R(0) : n) / d; }
+
 /* ---- vectors ------------------------------------------------------------------------------------- */
 /* dot = fma(a0,b0, fma(a1,b1, a2*b2)) */
 static inline real sp_dot3(const real a[3], const real b[3]) {
