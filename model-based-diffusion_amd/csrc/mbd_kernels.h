@@ -188,6 +188,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
   const float ang_damp = is_joint ? M->ang_damp[l] : 0.0f, vel_damp = is_joint ? M->vel_damp[l] : 0.0f;
   const int nr_eff = is_joint ? nr : -1;
   const int zero_lane = M->n_rot[0] < 0 ? base : (L < LPS ? base + L : -1);  // a lane contributing zeros
+  const bool need_child_mask = !(M->n_rot[0] < 0) && !(L < LPS);           // wave-uniform (scalar) flag
   float lim_lo[3], lim_hi[3], stiff[3], damp[3];
   v3 saxis[3];
   float sl_lo[3], sl_hi[3], sl_damp[3];
@@ -307,7 +308,12 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       // ---- (1) joints.acceleration_update ----------------------------------------------------------
       v3 Pp = shfl3(p, plane), Pv = shfl3(v, plane), Pw = shfl3(w, plane);
       q4 Pr = shfl4(r, plane);
-      if (world_parent) { Pp = mk3(0, 0, 0); Pv = mk3(0, 0, 0); Pw = mk3(0, 0, 0); Pr = q4{1, 0, 0, 0}; }
+      // a link hanging off the world sees the static identity frame. Only models with a jointed root need
+      // it (the generic kernels): a FREE root's joint is masked out, whatever parent data it computes with.
+      if constexpr (SLIDES) {
+        Pp = sel3(world_parent, mk3(0, 0, 0), Pp); Pv = sel3(world_parent, mk3(0, 0, 0), Pv);
+        Pw = sel3(world_parent, mk3(0, 0, 0), Pw); Pr = sel4(world_parent, q4{1, 0, 0, 0}, Pr);
+      }
       v3 fc_v, fc_w, fp_v, fp_w;
       {
         JointFrames f = joint_frames(jc, Pp, Pr, p, r);
@@ -350,7 +356,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
 #pragma unroll
       for (int c = 0; c < MAXCH; ++c) {
         v3 cv = shfl3(fp_v, child_src[c]), cw = shfl3(fp_w, child_src[c]);
-        if (zero_lane < 0) {  // no zero lane in this model: mask missing children (wave-uniform branch)
+        if (need_child_mask) {  // no zero lane in this model: mask missing children (scalar branch)
           cv = sel3(child_lane[c] >= 0, cv, mk3(0, 0, 0));
           cw = sel3(child_lane[c] >= 0, cw, mk3(0, 0, 0));
         }
@@ -367,7 +373,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       // ---- (3) joints.position_update (Jacobi) ------------------------------------------------------
       Pp = shfl3(p, plane);
       Pr = shfl4(r, plane);
-      if (world_parent) { Pp = mk3(0, 0, 0); Pr = q4{1, 0, 0, 0}; }
+      if constexpr (SLIDES) { Pp = sel3(world_parent, mk3(0, 0, 0), Pp); Pr = sel4(world_parent, q4{1, 0, 0, 0}, Pr); }
       v3 dc_p, dc_th, dp_p, dp_th;
       {
         JointFrames f = joint_frames(jc, Pp, Pr, p, r);
@@ -390,7 +396,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         // angular alignment by joint type (0 hinges: weld; 1: Xc || Xp; 2: Yc _|_ Xp; 3: free)
         v3 A = sel3(nr == 1, f.Xc, f.Xp);
         v3 Bv = sel3(nr == 1, f.Xp, f.Yc);
-        float sc = nr_eff == 1 ? 1.0f : (nr_eff == 2 ? dot(f.Xp, f.Yc) : 0.0f);
+        const float dxy = dot(f.Xp, f.Yc);
+        float sc = nr_eff == 1 ? 1.0f : (nr_eff == 2 ? dxy : 0.0f);
         v3 e = scale(cross(A, Bv), sc);
         if constexpr (SLIDES) {  // joints without a hinge dof keep the child's orientation locked to the parent's
           q4 qe = qmul(f.aprot, conj(f.acrot));
@@ -425,8 +432,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         }
         ang_apply(ca, q_ta.y, js_ang, dth2);
         // joint limits on the Euler angles: three corrections, quotients (0,1) packed, 2 alone
-        auto viol_of = [&](int k, float a) {
-          float viol = a < lim_lo[k] ? a - lim_lo[k] : (a > lim_hi[k] ? a - lim_hi[k] : 0.0f);
+        auto viol_of = [&](int k, float a) {  // both differences first: selects, not branches
+          const float dlo = a - lim_lo[k], dhi = a - lim_hi[k];
+          float viol = a < lim_lo[k] ? dlo : (a > lim_hi[k] ? dhi : 0.0f);
           return k < nr_eff ? viol : 0.0f;
         };
         const AngPrep c0 = ang_prepare<ISO>(scale(f.Xp, -viol_of(0, f.ang0)), ip, ic, R2);
@@ -445,7 +453,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
 #pragma unroll
         for (int c = 0; c < MAXCH; ++c) {
           v3 cp = shfl3(dp_p, child_src[c]), cth = shfl3(dp_th, child_src[c]);
-          if (zero_lane < 0) {
+          if (need_child_mask) {
             cp = sel3(child_lane[c] >= 0, cp, mk3(0, 0, 0));
             cth = sel3(child_lane[c] >= 0, cth, mk3(0, 0, 0));
           }
