@@ -38,6 +38,8 @@ struct RolloutParams {
 };
 
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
+// one full LDS-counter wait after a batch of shuffles instead of a partial s_waitcnt before every consumer
+__device__ __forceinline__ void shfl_join() { __builtin_amdgcn_s_waitcnt(0xC07F); }
 __device__ __forceinline__ v3 shfl3(v3 v, int src) { return v3{shfl(v.x, src), shfl(v.y, src), shfl(v.z, src)}; }
 __device__ __forceinline__ q4 shfl4(q4 q, int src) {
   return q4{shfl(q.w, src), shfl(q.x, src), shfl(q.y, src), shfl(q.z, src)};
@@ -308,6 +310,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       // ---- (1) joints.acceleration_update ----------------------------------------------------------
       v3 Pp = shfl3(p, plane), Pv = shfl3(v, plane), Pw = shfl3(w, plane);
       q4 Pr = shfl4(r, plane);
+      shfl_join();
       // a link hanging off the world sees the static identity frame. Only models with a jointed root need
       // it (the generic kernels): a FREE root's joint is masked out, whatever parent data it computes with.
       if constexpr (SLIDES) {
@@ -353,14 +356,19 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       }
       // ---- (2) integrator.integrate_xdd -------------------------------------------------------------
       v3x2 acc = pack3(fc_v, fc_w);  // (linear, angular) acceleration, packed
+      {
+        v3 cv[MAXCH], cw[MAXCH];
 #pragma unroll
-      for (int c = 0; c < MAXCH; ++c) {
-        v3 cv = shfl3(fp_v, child_src[c]), cw = shfl3(fp_w, child_src[c]);
-        if (need_child_mask) {  // no zero lane in this model: mask missing children (scalar branch)
-          cv = sel3(child_lane[c] >= 0, cv, mk3(0, 0, 0));
-          cw = sel3(child_lane[c] >= 0, cw, mk3(0, 0, 0));
+        for (int c = 0; c < MAXCH; ++c) { cv[c] = shfl3(fp_v, child_src[c]); cw[c] = shfl3(fp_w, child_src[c]); }
+        shfl_join();
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+          if (need_child_mask) {  // no zero lane in this model: mask missing children (scalar branch)
+            cv[c] = sel3(child_lane[c] >= 0, cv[c], mk3(0, 0, 0));
+            cw[c] = sel3(child_lane[c] >= 0, cw[c], mk3(0, 0, 0));
+          }
+          acc = add2(acc, pack3(cv[c], cw[c]));
         }
-        acc = add2(acc, pack3(cv, cw));
       }
       const v3 av = lo3(acc), aw = hi3(acc);
       v = mk3(ffma(av.x + grav.x, dt, vel_fac * v.x), ffma(av.y + grav.y, dt, vel_fac * v.y),
@@ -373,6 +381,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       // ---- (3) joints.position_update (Jacobi) ------------------------------------------------------
       Pp = shfl3(p, plane);
       Pr = shfl4(r, plane);
+      shfl_join();
       if constexpr (SLIDES) { Pp = sel3(world_parent, mk3(0, 0, 0), Pp); Pr = sel4(world_parent, q4{1, 0, 0, 0}, Pr); }
       v3 dc_p, dc_th, dp_p, dp_th;
       {
@@ -450,14 +459,17 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       }
       {
         v3x2 acc = pack3(dc_p, dc_th);  // (translation, rotation vector), packed
+        v3 cp[MAXCH], cth[MAXCH];
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) { cp[c] = shfl3(dp_p, child_src[c]); cth[c] = shfl3(dp_th, child_src[c]); }
+        shfl_join();
 #pragma unroll
         for (int c = 0; c < MAXCH; ++c) {
-          v3 cp = shfl3(dp_p, child_src[c]), cth = shfl3(dp_th, child_src[c]);
           if (need_child_mask) {
-            cp = sel3(child_lane[c] >= 0, cp, mk3(0, 0, 0));
-            cth = sel3(child_lane[c] >= 0, cth, mk3(0, 0, 0));
+            cp[c] = sel3(child_lane[c] >= 0, cp[c], mk3(0, 0, 0));
+            cth[c] = sel3(child_lane[c] >= 0, cth[c], mk3(0, 0, 0));
           }
-          acc = add2(acc, pack3(cp, cth));
+          acc = add2(acc, pack3(cp[c], cth[c]));
         }
         p = add(p, lo3(acc));
         r = qrotvec_raw(r, hi3(acc));  // renormalised at the end of stage (4)
