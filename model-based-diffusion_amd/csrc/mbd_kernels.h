@@ -281,6 +281,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
     }
   };
   load_actions(0, u_rot, u_sl);
+  // the parent's POSE for the next substep is fetched as soon as it is final (end of stage 4), so that its
+  // LDS round trip overlaps the velocity stages; only the parent's velocities are fetched at the top
+  v3 Pp_next = shfl3(p, plane);
+  q4 Pr_next = shfl4(r, plane);
   float rew_sum = 0.0f;
 
   for (int t = 0; t < H; ++t) {
@@ -308,8 +312,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
 
     for (int fr = 0; fr < nfr; ++fr) {
       // ---- (1) joints.acceleration_update ----------------------------------------------------------
-      v3 Pp = shfl3(p, plane), Pv = shfl3(v, plane), Pw = shfl3(w, plane);
-      q4 Pr = shfl4(r, plane);
+      v3 Pv = shfl3(v, plane), Pw = shfl3(w, plane);
+      v3 Pp = Pp_next;
+      q4 Pr = Pr_next;
       shfl_join();
       // a link hanging off the world sees the static identity frame. Only models with a jointed root need
       // it (the generic kernels): a FREE root's joint is masked out, whatever parent data it computes with.
@@ -513,6 +518,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         }
         p = add(p, cd_p);  // zero corrections on links without colliders
         r = qrotvec(r, cd_th);
+        Pp_next = shfl3(p, plane);  // consumed by stage (1) of the next substep
+        Pr_next = shfl4(r, plane);
       }
       // ---- (5) integrator.project_xd ------------------------------------------------------------------
       const v3 v_old = v, w_old = w;
