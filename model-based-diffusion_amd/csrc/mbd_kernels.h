@@ -313,9 +313,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
     for (int fr = 0; fr < nfr; ++fr) {
       // ---- (1) joints.acceleration_update ----------------------------------------------------------
       v3 Pv = shfl3(v, plane), Pw = shfl3(w, plane);
-      v3 Pp = Pp_next;
+      v3 Pp = Pp_next;  // (no join here: the velocities are first needed after the joint frames)
       q4 Pr = Pr_next;
-      shfl_join();
       // a link hanging off the world sees the static identity frame. Only models with a jointed root need
       // it (the generic kernels): a FREE root's joint is masked out, whatever parent data it computes with.
       if constexpr (SLIDES) {
