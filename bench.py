@@ -111,6 +111,9 @@ def main():
     ap.add_argument("--no-final-reward", action="store_true")
     args = ap.parse_args()
 
+    # before the HIP runtime initialises: the host driver only supports dmabuf IPC (RCCL peer mappings)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -123,8 +126,6 @@ def main():
     backend = os.environ.get("MBD_DIST_BACKEND", "nccl")  # "gloo": 2-rank dry runs on a single-GPU box
     n_dev = torch.cuda.device_count()
     if distributed:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if backend == "nccl":
             assert n_dev >= world, f"{world} ranks need {world} GPUs, found {n_dev}"
             torch.cuda.set_device(local_rank)

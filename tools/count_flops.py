@@ -60,6 +60,9 @@ def main():
     res = {"instructions_per_substep": len(best), "valu_per_substep": sum(v for k, v in c.items() if k.startswith("v_")),
            "lds_instr_per_substep": sum(v for k, v in c.items() if k.startswith("ds_")), "fp32_flops_per_lane_substep": flops}
     print(json.dumps(res))
+    if "--hist" in sys.argv:
+        for k, v in c.most_common():
+            print(f"{v:5d} {k}")
     if "--write" in sys.argv:
         with open(os.path.join(ROOT, "profiles", "r01_static_flops.json"), "w") as f:
             json.dump(res, f, indent=1)
