@@ -18,9 +18,11 @@
  *   - threefry2x32: pinned by the three Random123 known-answer vectors (tests/test_oracle_prng.py).
  *   - schedule: pinned by the f32 known answers of SURVEY.md §8(a) row A0.
  *   - car2d: pinned by closed-form cases (tests/test_oracle_car2d.py).
- *   - split / random_bits layouts, uniform bit trick, ErfInv coefficients: restated from memory of the
- *     JAX/XLA sources, "parity unpinned" (no JAX here to generate vectors; tools/dump_golden.py
- *     produces them under a real jax install).
+ *   - split / random_bits layouts, uniform bit trick, normal, ErfInv coefficients: restated from the
+ *     JAX/XLA sources and pinned by outputs of the real JAX printed in its public documentation (key
+ *     splits and normal/uniform draws for PRNGKey(0)/PRNGKey(42) in the legacy layout and key(42) in the
+ *     partitionable layout; tests/test_oracle_prng.py lists values and sources) — reproduced bit for bit.
+ *     tools/dump_golden.py produces longer vectors under a real jax install.
  *
  * All arithmetic is float32 (the reference keeps jax_enable_x64 off, mbd_planner.py:13-14) except the
  * PRNG (uint32).

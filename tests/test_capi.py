@@ -44,6 +44,15 @@ def test_host_prng_matches_oracle(lib, orc):
                 assert np.array_equal(_capi.prng_split(k, num, impl), orc.split(k, num, impl))
 
 
+def test_host_prng_published_jax_key_splits(lib):
+    """mbd_prng_key / mbd_prng_split against key values printed in JAX's own documentation (see
+    tests/test_oracle_prng.py for the sources): legacy layout PRNGKey(0), partitionable layout key(42)."""
+    from mbd_hip import _capi
+    assert _capi.prng_split(_capi.prng_key(0), 2, 0).tolist() == [[4146024105, 967050713],
+                                                                  [2718843009, 1272950319]]
+    assert _capi.prng_split(_capi.prng_key(42), 2, 1)[0].tolist() == [1832780943, 270669613]
+
+
 def test_args_mirror_the_reference_dataclass():
     from mbd_hip.planners.mbd_planner import Args, apply_recommended
     a = Args()

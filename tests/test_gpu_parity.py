@@ -53,6 +53,36 @@ def test_prng_split_and_reset(gpu, orc, impl, monkeypatch):
         assert np.array_equal(np.asarray(st.pipeline_state).reshape(-1), ref.reshape(-1)), name
 
 
+@pytest.mark.parametrize("impl,seed,want", [(0, 42, [0.18693547, -1.2806505, -1.5593132]),
+                                            (1, 42, [-0.028304616, None, None])])
+def test_sample_kernel_reproduces_published_jax_normals(gpu, orc, impl, seed, want, monkeypatch):
+    """The device noise generator (sample_kernel: threefry -> bits -> uniform -> erf_inv) against normal
+    draws printed in JAX's documentation (sources: tests/test_oracle_prng.py). Y0s = 0 + 0.5 * eps is exact
+    in f32, so the published eps must come back bit for bit; entries the docs do not show are checked
+    against the oracle."""
+    import torch
+    monkeypatch.setenv("MBD_THREEFRY_PARTITIONABLE", str(impl))
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.path_integral import Args
+    from mbd_hip.planners.mbd_planner import Plan
+    env = get_env("hopper")  # Nu = 3: eps has shape (1, 1, 3), the same counters as shape (3,)
+    plan = Plan(env, Args(env_name="hopper", Nsample=1, Hsample=1, Nrefine=2), update_method=1)
+    plan.set_state0(env.reset(gpu.prng_key(0)))
+    plan.set_sigma(0.5)
+    key = gpu.prng_key(seed)
+    Ybar, loc = torch.zeros(3, device="cuda"), torch.zeros(1, device="cuda")
+    gpu.check(plan.lib.mbd_plan_sample_rollout(plan.h, 1, gpu.key_array(key), Ybar.data_ptr(), loc.data_ptr(),
+                                               None, None))
+    torch.cuda.synchronize()
+    eps = plan.peek()[0].reshape(3) * np.float32(2.0)
+    plan.close()
+    ref = orc.normal(key, (3,), impl)
+    assert np.array_equal(eps, ref)
+    for got, w in zip(eps, want):
+        if w is not None:
+            assert got == np.float32(w)
+
+
 @pytest.mark.parametrize("name,B,H,sigma", [("humanoidrun", 96, 50, 0.6), ("humanoidrun", 1, 3, 0.3),
                                             ("humanoidtrack", 64, 50, 0.4), ("hopper", 80, 50, 0.5),
                                             ("halfcheetah", 72, 50, 0.5), ("walker2d", 40, 50, 0.5),

@@ -81,3 +81,37 @@ def test_sample_rows_are_slices_of_the_global_tensor(orc):
         part = orc.sample(key, impl, 16, 6, 3, 5, 7, 0.3, Ybar)
         assert np.array_equal(full[5:12], part)
         assert np.abs(full).max() <= 1.0
+
+
+# ---- outputs of the real JAX, as printed in its public documentation ---------------------------------------
+# These are the only reference-side numbers for this path that exist outside a JAX install, and they pin
+# the whole noise chain of mbd_planner.py:97,103 (PRNGKey -> split -> random_bits -> uniform -> erf_inv):
+#   * "JAX - The Sharp Bits", section "Random numbers" (jax_threefry_partitionable=False, the default up to
+#     JAX 0.4.x): PRNGKey(0); normal(key, (1,)) = [-0.20584226]; split -> key [4146024105 967050713],
+#     subkey [2718843009 1272950319]; normal(subkey, (1,)) = [-1.2515389]; uniform(PRNGKey(0)) = 0.41845703
+#   * "Pseudorandom numbers" tutorial, old edition (PRNGKey(42), legacy layout): normal(key) = -0.18471177,
+#     normal(key, (3,)) "all at once" = [0.18693547 -1.2806505 -1.5593132]
+#   * the same tutorial, JAX >= 0.5 edition (key(42), jax_threefry_partitionable=True by default):
+#     normal(key) = -0.028304616; split -> new_key [1832780943 270669613]; normal(subkey) = 0.60576403
+JAX_DOC_LEGACY, JAX_DOC_PARTITIONABLE = 0, 1
+
+
+def test_published_jax_outputs_legacy_layout(orc):
+    k0 = orc.prng_key(0)
+    ks = orc.split(k0, 2, JAX_DOC_LEGACY)
+    assert ks.tolist() == [[4146024105, 967050713], [2718843009, 1272950319]]
+    assert orc.normal(k0, (1,), JAX_DOC_LEGACY)[0] == np.float32(-0.20584226)
+    assert orc.normal(ks[1], (1,), JAX_DOC_LEGACY)[0] == np.float32(-1.2515389)
+    assert orc.uniform(k0, 1, 0.0, 1.0, JAX_DOC_LEGACY)[0] == np.float32(0.41845703)
+    k42 = orc.prng_key(42)
+    assert orc.normal(k42, (1,), JAX_DOC_LEGACY)[0] == np.float32(-0.18471177)
+    assert np.array_equal(orc.normal(k42, (3,), JAX_DOC_LEGACY),
+                          np.array([0.18693547, -1.2806505, -1.5593132], np.float32))
+
+
+def test_published_jax_outputs_partitionable_layout(orc):
+    k42 = orc.prng_key(42)
+    assert orc.normal(k42, (1,), JAX_DOC_PARTITIONABLE)[0] == np.float32(-0.028304616)
+    ks = orc.split(k42, 2, JAX_DOC_PARTITIONABLE)
+    assert ks[0].tolist() == [1832780943, 270669613]
+    assert orc.normal(ks[1], (1,), JAX_DOC_PARTITIONABLE)[0] == np.float32(0.60576403)
