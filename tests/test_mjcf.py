@@ -37,6 +37,18 @@ def test_humanoid_topology_matches_survey_d1():
     assert np.allclose(F["rot_lo"][4, 0], math.radians(-160)) and np.allclose(F["rot_hi"][4, 0], math.radians(-2))
 
 
+def test_humanoid_masses_match_mujoco_body_mass():
+    """MuJoCo's compile of the same humanoid (Gym/Brax `humanoid.xml`; `model.body_mass` as printed by
+    mujoco and quoted in Gymnasium's Humanoid docs): torso 8.90746237, lwaist 2.26194671, pelvis 6.61619411,
+    thigh 4.75175093, shin 2.75569617 + foot 1.76714587 (Brax fuses the foot sphere into the shin link),
+    upper arm 1.66108048, lower arm 1.22954017.  The MJCF compiler here must reproduce them from the geoms
+    (default density 1000)."""
+    m = load_model("humanoidrun")
+    want = [8.90746237, 2.26194671, 6.61619411, 4.75175093, 2.75569617 + 1.76714587, 4.75175093,
+            2.75569617 + 1.76714587, 1.66108048, 1.22954017, 1.66108048, 1.22954017]
+    assert np.allclose(1.0 / m.fields["inv_mass"][:11], want, rtol=2e-6)
+
+
 def test_humanoidtrack_drops_marker_links_and_tracks_five_bodies():
     m = load_model("humanoidtrack")
     assert m.n_links == 11 and m.fields["n_frames"] == 5
