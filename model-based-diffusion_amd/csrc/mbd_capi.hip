@@ -71,6 +71,7 @@ struct mbd_env {
   float rew_xref = 0.0f;
   int lps = 16, max_children = 0, max_col = 0;
   bool slides = false;
+  bool slide_limits = false;  // any slide dof with a finite range
   // scratch for the single-env step path
   float *d_s_in = nullptr, *d_act = nullptr, *d_s_out = nullptr, *d_rew = nullptr;
   int state_size() const { return kind == ENV_CAR2D ? 3 : model.n_links * MBD_LINK_STATE; }
@@ -105,7 +106,8 @@ int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B
     HIP_TRY(hipGetLastError());
     return MBD_OK;
   }
-  RolloutParams P{env->d_model, d_state0, d_us, d_rewss, d_rews, d_xpos, d_state_final, B, H, g_dbg_clock};
+  RolloutParams P{env->d_model, d_state0, d_us, d_rewss, d_rews, d_xpos, d_state_final, B, H,
+                  env->slide_limits ? 1 : 0, env->max_children, g_dbg_clock};
   const bool iso = env->model.iso_inertia != 0;
   const int spw = 64 / env->lps;
   dim3 grid((B + spw - 1) / spw), block(64);
@@ -115,6 +117,8 @@ int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B
     MBD_LAUNCH(16, true, false, 3, 1);  // the humanoid (metric config)
   } else if (env->lps == 16 && iso && !env->slides && env->max_children <= 3 && env->max_col <= 5) {
     MBD_LAUNCH(16, true, false, 3, 5);  // humanoidstandup: up to 5 sphere colliders on one link
+  } else if (env->lps == 16 && iso && !env->slides && env->max_col <= 2) {
+    MBD_LAUNCH(16, true, false, 4, 2);  // ant: free root with four legs, no slide / weld joints
   } else if (env->lps == 16) {
     if (iso) MBD_LAUNCH(16, true, true, 4, 2); else MBD_LAUNCH(16, false, true, 4, 2);
   } else if (env->lps == 8) {
@@ -298,6 +302,8 @@ extern "C" int mbd_env_create_model(const char* env_name, int device, const mbd_
   for (int l = 0; l < m.n_links; ++l) {
     if (m.parent[l] >= 0) nch[m.parent[l]]++;
     if (m.n_slide[l] > 0 || m.n_rot[l] == 0) e->slides = true;  // slides and welds both need the generic kernels
+    for (int k = 0; k < m.n_slide[l]; ++k)
+      if (m.slide_lo[l][k] > -1e8f || m.slide_hi[l][k] < 1e8f) e->slide_limits = true;
   }
   for (int k = 0; k < m.n_col; ++k) ncl[m.col_link[k]]++;
   for (int l = 0; l < m.n_links; ++l) {

@@ -34,6 +34,8 @@ struct RolloutParams {
   float* xpos;               // [B][H][K][3] or nullptr
   float* state_final;        // [B][L][13] or nullptr
   int B, H;
+  int slide_limits;  // any slide dof with a finite range (wave-uniform: the limit corrections are skipped otherwise)
+  int max_children;  // largest child count in the model (wave-uniform bound of the generic kernels' child loops)
   unsigned long long* dbg_clock;  // nullptr, or [grid][3] = (start tick, end tick, HW_ID|XCC<<32) (tools/probes)
 };
 
@@ -50,18 +52,47 @@ struct Inert {
   float inv_mass;
   float ib[ISO ? 1 : 6];
 };
+// World-frame inverse inertia W = R Ib R^T (xx yy zz xy xz yz) of a link at orientation r: T = R Ib, then
+// the six unique entries of T R^T.  Refreshed at the head of every stage that applies it — (1), (3), (4),
+// (6) — and applied as a symmetric 3x3 product (9 FMAs instead of two quaternion rotations around the
+// body-frame product).  Isotropic models (ib0 * identity) carry nothing.
+template <bool ISO>
+struct WInert {
+  float w[ISO ? 1 : 6];
+};
+template <bool ISO>
+__device__ __forceinline__ WInert<ISO> world_inertia(const Inert<ISO>& in, q4 r) {
+  WInert<ISO> W;
+  if constexpr (ISO) {
+    W.w[0] = 0.0f;
+  } else {
+    const axes3 A = qaxes(r);
+    const float xx = in.ib[0], yy = in.ib[1], zz = in.ib[2], xy = in.ib[3], xz = in.ib[4], yz = in.ib[5];
+    auto row = [&](float X, float Y, float Z) {  // row i of T = R Ib
+      return v3{ffma(Z, xz, ffma(Y, xy, X * xx)), ffma(Z, yz, ffma(Y, yy, X * xy)), ffma(Z, zz, ffma(Y, yz, X * xz))};
+    };
+    const v3 T0 = row(A.X.x, A.Y.x, A.Z.x), T1 = row(A.X.y, A.Y.y, A.Z.y), T2 = row(A.X.z, A.Y.z, A.Z.z);
+    auto ent = [&](v3 T, float X, float Y, float Z) { return ffma(T.z, Z, ffma(T.y, Y, T.x * X)); };
+    W.w[0] = ent(T0, A.X.x, A.Y.x, A.Z.x);
+    W.w[1] = ent(T1, A.X.y, A.Y.y, A.Z.y);
+    W.w[2] = ent(T2, A.X.z, A.Y.z, A.Z.z);
+    W.w[3] = ent(T0, A.X.y, A.Y.y, A.Z.y);
+    W.w[4] = ent(T0, A.X.z, A.Y.z, A.Z.z);
+    W.w[5] = ent(T1, A.X.z, A.Y.z, A.Z.z);
+  }
+  return W;
+}
 // world-frame inverse inertia applied to v
 template <bool ISO>
-__device__ __forceinline__ v3 iinv(const Inert<ISO>& in, q4 r, v3 v) {
+__device__ __forceinline__ v3 iinv(const Inert<ISO>& in, const WInert<ISO>& W, v3 v) {
   if constexpr (ISO) {
     return scale(v, in.ib[0]);
   } else {
-    v3 l = irot(v, r);
     v3 m;
-    m.x = ffma(in.ib[4], l.z, ffma(in.ib[3], l.y, in.ib[0] * l.x));
-    m.y = ffma(in.ib[5], l.z, ffma(in.ib[1], l.y, in.ib[3] * l.x));
-    m.z = ffma(in.ib[2], l.z, ffma(in.ib[5], l.y, in.ib[4] * l.x));
-    return rot(m, r);
+    m.x = ffma(W.w[4], v.z, ffma(W.w[3], v.y, W.w[0] * v.x));
+    m.y = ffma(W.w[5], v.z, ffma(W.w[1], v.y, W.w[3] * v.x));
+    m.z = ffma(W.w[2], v.z, ffma(W.w[5], v.y, W.w[4] * v.x));
+    return m;
   }
 }
 
@@ -92,12 +123,15 @@ __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp,
   struct { v3 X, Y, Z; } A{lo3(AX.X), lo3(AX.Y), lo3(AX.Z)}, C{hi3(AX.X), hi3(AX.Y), hi3(AX.Z)};
   f.Xp = A.X; f.Xc = C.X; f.Yc = C.Y; f.Zc = C.Z;
   // sin b = Zc.Xp; (sin a, cos a) and (sin c, cos c) both have length cos b: one reciprocal for all
-  float sb = fclip(dot(C.Z, A.X), -1.0f, 1.0f);
+  // (opaque: keeps the SLP vectoriser from pairing these five dot products across register pairs, which
+  // costs more v_mov than the packed ops save — 15 instructions per substep)
+  auto opq = [](float x) { asm("" : "+v"(x)); return x; };
+  float sb = fclip(opq(dot(C.Z, A.X)), -1.0f, 1.0f);
   float cb2 = ffma(-sb, sb, 1.0f);
   float cb = fsqrt(cb2 < 0.0f ? 0.0f : cb2);
   float inv = div_(1.0f, cb + 1e-10f);
-  const f2 a02 = angle_unit2(mk2(-dot(C.Z, A.Y) * inv, -dot(C.Y, A.X) * inv),
-                             mk2(dot(C.Z, A.Z) * inv, dot(C.X, A.X) * inv));
+  const f2 a02 = angle_unit2(mk2(-opq(dot(C.Z, A.Y)) * inv, -opq(dot(C.Y, A.X)) * inv),
+                             mk2(opq(dot(C.Z, A.Z)) * inv, opq(dot(C.X, A.X)) * inv));
   f.ang0 = a02.x;
   f.ang1 = angle_unit(sb, cb);
   f.ang2 = a02.y;
@@ -106,19 +140,45 @@ __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp,
   return f;
 }
 
-// (parent, child) pair of inverse-inertia applications: low half with the parent's tensor/orientation,
-// high half with the child's
+// (parent, child) pair of world tensors and of inverse-inertia applications: low half the parent's, high half
+// the child's
 template <bool ISO>
-__device__ __forceinline__ v3x2 iinv2(const Inert<ISO>& ip, const Inert<ISO>& ic, q4x2 R2, v3x2 v) {
+struct WInert2 {
+  f2 w[ISO ? 1 : 6];
+};
+template <bool ISO>
+__device__ __forceinline__ WInert2<ISO> world_inertia2(const Inert<ISO>& ip, const Inert<ISO>& ic, q4x2 R2) {
+  WInert2<ISO> W;
+  if constexpr (ISO) {
+    W.w[0] = mk2(0.0f, 0.0f);
+  } else {
+    const axes3x2 A = qaxes2(R2);
+    const f2 xx = mk2(ip.ib[0], ic.ib[0]), yy = mk2(ip.ib[1], ic.ib[1]), zz = mk2(ip.ib[2], ic.ib[2]);
+    const f2 xy = mk2(ip.ib[3], ic.ib[3]), xz = mk2(ip.ib[4], ic.ib[4]), yz = mk2(ip.ib[5], ic.ib[5]);
+    auto row = [&](f2 X, f2 Y, f2 Z) {
+      return v3x2{fma2(Z, xz, fma2(Y, xy, X * xx)), fma2(Z, yz, fma2(Y, yy, X * xy)), fma2(Z, zz, fma2(Y, yz, X * xz))};
+    };
+    const v3x2 T0 = row(A.X.x, A.Y.x, A.Z.x), T1 = row(A.X.y, A.Y.y, A.Z.y), T2 = row(A.X.z, A.Y.z, A.Z.z);
+    auto ent = [&](v3x2 T, f2 X, f2 Y, f2 Z) { return fma2(T.z, Z, fma2(T.y, Y, T.x * X)); };
+    W.w[0] = ent(T0, A.X.x, A.Y.x, A.Z.x);
+    W.w[1] = ent(T1, A.X.y, A.Y.y, A.Z.y);
+    W.w[2] = ent(T2, A.X.z, A.Y.z, A.Z.z);
+    W.w[3] = ent(T0, A.X.y, A.Y.y, A.Z.y);
+    W.w[4] = ent(T0, A.X.z, A.Y.z, A.Z.z);
+    W.w[5] = ent(T1, A.X.z, A.Y.z, A.Z.z);
+  }
+  return W;
+}
+template <bool ISO>
+__device__ __forceinline__ v3x2 iinv2(const Inert<ISO>& ip, const Inert<ISO>& ic, const WInert2<ISO>& W, v3x2 v) {
   if constexpr (ISO) {
     return scale2(v, mk2(ip.ib[0], ic.ib[0]));
   } else {
-    q4x2 Rc{R2.w, -R2.x, -R2.y, -R2.z};
-    v3x2 l = rot2(v, Rc), m;
-    m.x = fma2(mk2(ip.ib[4], ic.ib[4]), l.z, fma2(mk2(ip.ib[3], ic.ib[3]), l.y, mk2(ip.ib[0], ic.ib[0]) * l.x));
-    m.y = fma2(mk2(ip.ib[5], ic.ib[5]), l.z, fma2(mk2(ip.ib[1], ic.ib[1]), l.y, mk2(ip.ib[3], ic.ib[3]) * l.x));
-    m.z = fma2(mk2(ip.ib[2], ic.ib[2]), l.z, fma2(mk2(ip.ib[5], ic.ib[5]), l.y, mk2(ip.ib[4], ic.ib[4]) * l.x));
-    return rot2(m, R2);
+    v3x2 m;
+    m.x = fma2(W.w[4], v.z, fma2(W.w[3], v.y, W.w[0] * v.x));
+    m.y = fma2(W.w[5], v.z, fma2(W.w[1], v.y, W.w[3] * v.x));
+    m.z = fma2(W.w[2], v.z, fma2(W.w[5], v.y, W.w[4] * v.x));
+    return m;
   }
 }
 // one angular positional correction (rotate child by +e, parent by -e): I^-1 e * |e|^2 /
@@ -129,10 +189,11 @@ struct AngPrep {
   float num, den;
 };
 template <bool ISO>
-__device__ __forceinline__ AngPrep ang_prepare(v3 e, const Inert<ISO>& ip, const Inert<ISO>& ic, q4x2 R2) {
+__device__ __forceinline__ AngPrep ang_prepare(v3 e, const Inert<ISO>& ip, const Inert<ISO>& ic,
+                                               const WInert2<ISO>& W2) {
   AngPrep a;
   v3x2 e2 = bcast3(e);
-  a.in2 = iinv2<ISO>(ip, ic, R2, e2);
+  a.in2 = iinv2<ISO>(ip, ic, W2, e2);
   f2 d2 = dot2(e2, a.in2);
   a.den = (d2.x + d2.y) + 1e-20f;
   a.num = dot(e, e);
@@ -230,6 +291,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
   int child_src[MAXCH];  // lane to pull child c's contribution from (a zero lane when there is none)
 #pragma unroll
   for (int c = 0; c < MAXCH; ++c) child_src[c] = child_lane[c] >= 0 ? child_lane[c] : (zero_lane >= 0 ? zero_lane : lane);
+  // the generic kernels (MAXCH = 4) bound their child loops by the model's largest child count: a scalar
+  // branch per slot; a skipped slot would have added exact zeros
+  const int max_children = P.max_children;
+  auto child_slot = [&](int c) { return MAXCH <= 3 || c < max_children; };
   v3 col_pos[MAXCOL];
   float col_rad[MAXCOL];
   bool col_has[MAXCOL];
@@ -324,7 +389,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       v3 fc_v, fc_w, fp_v, fp_w;
       {
         JointFrames f = joint_frames(jc, Pp, Pr, p, r);
-        const q4x2 R2 = pack4(Pr, r);
+        const WInert2<ISO> W2 = world_inertia2<ISO>(ip, ic, pack4(Pr, r));
         const v3x2 arm = sub2(f.anchor, pack3(Pp, p));                 // (rp, rc)
         const v3x2 va = add2(pack3(Pv, v), cross2(pack3(Pw, w), arm));  // anchor velocities (vp, vc)
         v3 rel_v = sub(hi3(va), lo3(va)), rel_w = sub(w, Pw);
@@ -354,7 +419,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         const v3x2 F2 = bcast3(F);
         const v3x2 lin = scale2(F2, mk2(-ip.inv_mass, ic.inv_mass));       // (fp_v, fc_v)
         const v3x2 tot = add2(bcast3(T), cross2(arm, F2));
-        const v3x2 ang = scale2(iinv2<ISO>(ip, ic, R2, tot), mk2(-1.0f, 1.0f));  // (fp_w, fc_w)
+        const v3x2 ang = scale2(iinv2<ISO>(ip, ic, W2, tot), mk2(-1.0f, 1.0f));  // (fp_w, fc_w)
         fc_v = hi3(lin); fp_v = lo3(lin);
         fc_w = hi3(ang); fp_w = lo3(ang);
       }
@@ -363,10 +428,13 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       {
         v3 cv[MAXCH], cw[MAXCH];
 #pragma unroll
-        for (int c = 0; c < MAXCH; ++c) { cv[c] = shfl3(fp_v, child_src[c]); cw[c] = shfl3(fp_w, child_src[c]); }
+        for (int c = 0; c < MAXCH; ++c) {
+          if (child_slot(c)) { cv[c] = shfl3(fp_v, child_src[c]); cw[c] = shfl3(fp_w, child_src[c]); }
+        }
         shfl_join();
 #pragma unroll
         for (int c = 0; c < MAXCH; ++c) {
+          if (!child_slot(c)) continue;
           if (need_child_mask) {  // no zero lane in this model: mask missing children (scalar branch)
             cv[c] = sel3(child_lane[c] >= 0, cv[c], mk3(0, 0, 0));
             cw[c] = sel3(child_lane[c] >= 0, cw[c], mk3(0, 0, 0));
@@ -399,12 +467,12 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
             d = axpy(cf, s, d);
           }
         }
-        const q4x2 R2 = pack4(Pr, r);
+        const WInert2<ISO> W2 = world_inertia2<ISO>(ip, ic, pack4(Pr, r));
         const v3x2 arm = sub2(f.anchor, pack3(Pp, p));  // (rp, rc)
         float c2 = dot(d, d);
         const v3x2 d2 = bcast3(d);
         const v3x2 cr = cross2(arm, d2);                       // (rp x d, rc x d)
-        const f2 wq = dot2(cr, iinv2<ISO>(ip, ic, R2, cr));
+        const f2 wq = dot2(cr, iinv2<ISO>(ip, ic, W2, cr));
         float den = ffma(invm_sum, c2, wq.x + wq.y) + 1e-20f;
         // angular alignment by joint type (0 hinges: weld; 1: Xc || Xp; 2: Yc _|_ Xp; 3: free)
         v3 A = sel3(nr == 1, f.Xc, f.Xp);
@@ -417,14 +485,16 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           float sg = qe.w < 0.0f ? -2.0f : 2.0f;
           e = sel3(nr_eff == 0, mk3(sg * qe.x, sg * qe.y, sg * qe.z), e);
         }
-        const AngPrep ca = ang_prepare<ISO>(e, ip, ic, R2);
+        const AngPrep ca = ang_prepare<ISO>(e, ip, ic, W2);
         const f2 q_ta = div2_(mk2(c2, ca.num), mk2(den, ca.den));  // translation and alignment quotients
         float g = q_ta.x * js_pos;
         const v3x2 P2 = bcast3(scale(d, g));
         const v3x2 lin = scale2(P2, mk2(-ip.inv_mass, ic.inv_mass));  // (dp_p, dc_p)
-        v3x2 dth2 = scale2(iinv2<ISO>(ip, ic, R2, cross2(arm, P2)), mk2(-1.0f, 1.0f));  // (dp_th, dc_th)
+        v3x2 dth2 = scale2(iinv2<ISO>(ip, ic, W2, cross2(arm, P2)), mk2(-1.0f, 1.0f));  // (dp_th, dc_th)
         v3x2 lin2 = lin;
-        if constexpr (SLIDES) {  // slide limits: push the child back along the slide axis by the violation
+        // slide limits: push the child back along the slide axis by the violation. Models without a limited
+        // slide (planar roots of hopper / walker2d / halfcheetah) skip the block: it would add exact zeros.
+        if (SLIDES && P.slide_limits) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             v3 sx = rot(saxis[k], f.aprot);
@@ -435,12 +505,12 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
             float l2 = dot(dl, dl);
             const v3x2 dl2 = bcast3(dl);
             const v3x2 lcr = cross2(arm, dl2);
-            const f2 lw = dot2(lcr, iinv2<ISO>(ip, ic, R2, lcr));
+            const f2 lw = dot2(lcr, iinv2<ISO>(ip, ic, W2, lcr));
             float dens = ffma(invm_sum, l2, lw.x + lw.y);
             float gs = div_(l2, dens + 1e-20f) * js_pos;
             const v3x2 Ps2 = bcast3(scale(dl, gs));
             lin2 = add2(lin2, scale2(Ps2, mk2(-ip.inv_mass, ic.inv_mass)));
-            dth2 = add2(dth2, scale2(iinv2<ISO>(ip, ic, R2, cross2(arm, Ps2)), mk2(-1.0f, 1.0f)));
+            dth2 = add2(dth2, scale2(iinv2<ISO>(ip, ic, W2, cross2(arm, Ps2)), mk2(-1.0f, 1.0f)));
           }
         }
         ang_apply(ca, q_ta.y, js_ang, dth2);
@@ -450,9 +520,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           float viol = a < lim_lo[k] ? dlo : (a > lim_hi[k] ? dhi : 0.0f);
           return k < nr_eff ? viol : 0.0f;
         };
-        const AngPrep c0 = ang_prepare<ISO>(scale(f.Xp, -viol_of(0, f.ang0)), ip, ic, R2);
-        const AngPrep c1 = ang_prepare<ISO>(scale(f.ax1, -viol_of(1, f.ang1)), ip, ic, R2);
-        const AngPrep c2_ = ang_prepare<ISO>(scale(f.Zc, -viol_of(2, f.ang2)), ip, ic, R2);
+        const AngPrep c0 = ang_prepare<ISO>(scale(f.Xp, -viol_of(0, f.ang0)), ip, ic, W2);
+        const AngPrep c1 = ang_prepare<ISO>(scale(f.ax1, -viol_of(1, f.ang1)), ip, ic, W2);
+        const AngPrep c2_ = ang_prepare<ISO>(scale(f.Zc, -viol_of(2, f.ang2)), ip, ic, W2);
         const f2 q01 = div2_(mk2(c0.num, c1.num), mk2(c0.den, c1.den));
         const float q2 = div_(c2_.num, c2_.den);
         ang_apply(c0, q01.x, js_ang, dth2);
@@ -465,10 +535,13 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         v3x2 acc = pack3(dc_p, dc_th);  // (translation, rotation vector), packed
         v3 cp[MAXCH], cth[MAXCH];
 #pragma unroll
-        for (int c = 0; c < MAXCH; ++c) { cp[c] = shfl3(dp_p, child_src[c]); cth[c] = shfl3(dp_th, child_src[c]); }
+        for (int c = 0; c < MAXCH; ++c) {
+          if (child_slot(c)) { cp[c] = shfl3(dp_p, child_src[c]); cth[c] = shfl3(dp_th, child_src[c]); }
+        }
         shfl_join();
 #pragma unroll
         for (int c = 0; c < MAXCH; ++c) {
+          if (!child_slot(c)) continue;
           if (need_child_mask) {
             cp[c] = sel3(child_lane[c] >= 0, cp[c], mk3(0, 0, 0));
             cth[c] = sel3(child_lane[c] >= 0, cth[c], mk3(0, 0, 0));
@@ -483,6 +556,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       float con_dlam[MAXCOL];
       bool con_act[MAXCOL];
       {
+        const WInert<ISO> Wc = world_inertia<ISO>(ic, r);  // (r not yet renormalised, like the contact points)
         v3 cd_p = mk3(0, 0, 0), cd_th = mk3(0, 0, 0);
 #pragma unroll
         for (int j = 0; j < MAXCOL; ++j) {
@@ -492,7 +566,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           v3 pos = mk3(ctr.x, ctr.y, ctr.z - ffma(-0.5f, pen, col_rad[j]));
           v3 rc = sub(pos, p);
           v3 cn = crossz(rc);
-          v3 icn = iinv<ISO>(ic, r, cn);
+          v3 icn = iinv<ISO>(ic, Wc, cn);
           float wn = ic.inv_mass + dot(cn, icn);
           // (dlam and gt share one packed division below)
           v3 rl = irot(rc, r);
@@ -501,7 +575,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           dx.z = 0.0f;
           float ct2 = ffma(dx.x, dx.x, dx.y * dx.y);
           v3 cnt = cross(rc, dx);
-          v3 icnt = iinv<ISO>(ic, r, cnt);
+          v3 icnt = iinv<ISO>(ic, Wc, cnt);
           float dent = ffma(ic.inv_mass, ct2, dot(cnt, icnt));
           const f2 q_ng = div2_(mk2(pen, ct2), mk2(wn, dent + 1e-20f));
           float dlam = q_ng.x * coll_scale;
@@ -510,7 +584,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           float lim = mu * dlam;
           Pimp = sel3((ct2 * gt) * gt < lim * lim, axpy(-gt, dx, Pimp), Pimp);
           v3 ncd_p = axpy(ic.inv_mass, Pimp, cd_p);
-          v3 ncd_th = add(cd_th, iinv<ISO>(ic, r, cross(rc, Pimp)));
+          v3 ncd_th = add(cd_th, iinv<ISO>(ic, Wc, cross(rc, Pimp)));
           cd_p = sel3(active, ncd_p, cd_p);
           cd_th = sel3(active, ncd_th, cd_th);
           con_pos[j] = pos; con_dlam[j] = dlam; con_act[j] = active;
@@ -529,6 +603,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         w = mk3(dq.x * s, dq.y * s, dq.z * s);
       }
       // ---- (6) collisions.resolve_velocity --------------------------------------------------------------
+      const WInert<ISO> Wc = world_inertia<ISO>(ic, r);
 #pragma unroll
       for (int j = 0; j < MAXCOL; ++j) {
         v3 rc = sub(con_pos[j], p);
@@ -543,7 +618,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         float inv = div_(1.0f, vtn + 1e-10f);
         v3 dir = scale(vt, inv);
         v3 cn = crossz(rc), cdv = cross(rc, dir);
-        v3 icn = iinv<ISO>(ic, r, cn), icd = iinv<ISO>(ic, r, cdv);
+        v3 icn = iinv<ISO>(ic, Wc, cn), icd = iinv<ISO>(ic, Wc, cdv);
         float wn = ic.inv_mass + dot(cn, icn), wt = ic.inv_mass + dot(cdv, icd);
         float rest = -elast * vn_prev;
         float dvn = fmin_(rest, 0.0f) - vn;
@@ -554,7 +629,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         v3 Pimp = scale(dir, jt);
         Pimp.z = Pimp.z + jn;
         v3 nv = axpy(ic.inv_mass, Pimp, v);
-        v3 nw = add(w, iinv<ISO>(ic, r, cross(rc, Pimp)));
+        v3 nw = add(w, iinv<ISO>(ic, Wc, cross(rc, Pimp)));
         v = sel3(con_act[j], nv, v);
         w = sel3(con_act[j], nw, w);
       }

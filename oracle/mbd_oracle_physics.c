@@ -44,21 +44,41 @@ typedef struct { real v[3]; real w[3]; } mo_t;
 typedef struct {
   real inv_mass;
   real ib[6];    /* body-frame inverse inertia xx yy zz xy xz yz */
-  const real* r; /* orientation */
+  real W[6];     /* world-frame inverse inertia R Ib R^T (xx yy zz xy xz yz), see inert_refresh() */
   int iso;       /* model-wide: inverse inertia is ib[0] * identity */
   int world;     /* the static world: everything is zero */
 } inert_t;
 
-/* world-frame inverse inertia applied to v: R * Ib * R^T v  (iso: ib0 * v) */
+/* World-frame inverse inertia of a link at orientation r: W = R Ib R^T with R = (X Y Z) the axes of r,
+ * T = R Ib first, then the six unique entries of T R^T (com.inv_inertia in Brax).  Re-evaluated at the
+ * head of every stage that applies it — (1), (3), (4), (6) — from the orientation current there; inside
+ * a stage the Jacobi solves all see that same tensor.  Isotropic models never call it. */
+static void inert_refresh(inert_t* in, const real r[4]) {
+  if (in->iso || in->world) return;
+  real X[3], Y[3], Z[3], T[3][3];
+  sp_qaxes(r, X, Y, Z);
+  const real xx = in->ib[0], yy = in->ib[1], zz = in->ib[2], xy = in->ib[3], xz = in->ib[4], yz = in->ib[5];
+  for (int i = 0; i < 3; ++i) {
+    T[i][0] = sp_fma(Z[i], xz, sp_fma(Y[i], xy, X[i] * xx));
+    T[i][1] = sp_fma(Z[i], yz, sp_fma(Y[i], yy, X[i] * xy));
+    T[i][2] = sp_fma(Z[i], zz, sp_fma(Y[i], yz, X[i] * xz));
+  }
+#define ORC_W(i, j) sp_fma(T[i][2], Z[j], sp_fma(T[i][1], Y[j], T[i][0] * X[j]))
+  in->W[0] = ORC_W(0, 0); in->W[1] = ORC_W(1, 1); in->W[2] = ORC_W(2, 2);
+  in->W[3] = ORC_W(0, 1); in->W[4] = ORC_W(0, 2); in->W[5] = ORC_W(1, 2);
+#undef ORC_W
+}
+
+/* world-frame inverse inertia applied to v: W v  (iso: ib0 * v) */
 static inline void iinv_apply(const inert_t* in, const real v[3], real o[3]) {
   if (in->world) { sp_set3(o, 0, 0, 0); return; }
   if (in->iso) { sp_scale3(v, in->ib[0], o); return; }
-  real l[3], m[3];
-  sp_irot(v, in->r, l);
-  m[0] = sp_fma(in->ib[4], l[2], sp_fma(in->ib[3], l[1], in->ib[0] * l[0]));
-  m[1] = sp_fma(in->ib[5], l[2], sp_fma(in->ib[1], l[1], in->ib[3] * l[0]));
-  m[2] = sp_fma(in->ib[2], l[2], sp_fma(in->ib[5], l[1], in->ib[4] * l[0]));
-  sp_rot(m, in->r, o);
+  const real* W = in->W;
+  real m[3];
+  m[0] = sp_fma(W[4], v[2], sp_fma(W[3], v[1], W[0] * v[0]));
+  m[1] = sp_fma(W[5], v[2], sp_fma(W[1], v[1], W[3] * v[0]));
+  m[2] = sp_fma(W[2], v[2], sp_fma(W[5], v[1], W[4] * v[0]));
+  sp_copy3(m, o);
 }
 
 /* joint frames of link l given parent pose P and child pose C (kinematics.world_to_joint) */
@@ -138,13 +158,13 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
   for (int l = 0; l < L; ++l) {
     in[l].inv_mass = R(m->inv_mass[l]);
     for (int k = 0; k < 6; ++k) in[l].ib[k] = R(m->inv_inertia[l][k]);
-    in[l].r = x[l].r;
     in[l].iso = m->iso_inertia;
     in[l].world = 0;
+    inert_refresh(&in[l], x[l].r); /* stage (1) */
   }
   inert_t* world_in = &in[MBD_MAX_LINKS];
   memset(world_in, 0, sizeof(*world_in));
-  world_in->r = WORLD_X.r; world_in->world = 1;
+  world_in->world = 1;
 
   /* ---- (1) joints.acceleration_update: actuator torque, joint spring/damping, constraint damping */
   real fc_v[MBD_MAX_LINKS][3], fc_w[MBD_MAX_LINKS][3]; /* acceleration of the child from its own joint */
@@ -205,6 +225,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_qrotvec(x[l].r, th);
   }
   /* ---- (3) joints.position_update (Jacobi: every joint sees the same post-integration poses) */
+  for (int l = 0; l < L; ++l) inert_refresh(&in[l], x[l].r);
   real dc_p[MBD_MAX_LINKS][3], dc_th[MBD_MAX_LINKS][3], dp_p[MBD_MAX_LINKS][3], dp_th[MBD_MAX_LINKS][3];
   memset(dc_p, 0, sizeof(dc_p)); memset(dc_th, 0, sizeof(dc_th));
   memset(dp_p, 0, sizeof(dp_p)); memset(dp_th, 0, sizeof(dp_th));
@@ -299,6 +320,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_qrotvec_raw(x[l].r, dth); /* renormalised at the end of stage (4) */
   }
   /* ---- (4) geometry.contact (sphere-plane) + collisions.resolve_position */
+  for (int l = 0; l < L; ++l) inert_refresh(&in[l], x[l].r); /* (not yet renormalised, like the contact points) */
   contact_t con[MBD_MAX_COL];
   real cd_p[MBD_MAX_LINKS][3], cd_th[MBD_MAX_LINKS][3];
   int has_col[MBD_MAX_LINKS];
@@ -355,6 +377,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     for (int i = 0; i < 3; ++i) xd[l].w[i] = dq[1 + i] * s;
   }
   /* ---- (6) collisions.resolve_velocity: restitution + dynamic friction at active contacts */
+  for (int l = 0; l < L; ++l) inert_refresh(&in[l], x[l].r);
   for (int k = 0; k < m->n_col; ++k) {
     if (!con[k].active) continue;
     const int l = m->col_link[k];
