@@ -567,7 +567,7 @@ extern "C" int mbd_plan_score_update(mbd_plan* p, int i, const uint32_t key_samp
   HIP_TRY(hipSetDevice(p->env->device));
   hipStream_t s = (hipStream_t)stream_;
   const int N = c.Nsample, HNu = p->HNu;
-  hipLaunchKernelGGL(score_kernel, dim3(1), dim3(64), sizeof(float) * (size_t)N, s, d_rews_all,
+  hipLaunchKernelGGL(score_kernel, dim3(1), dim3(kScoreThreads), sizeof(float) * (size_t)N, s, d_rews_all,
                      c.enable_demo ? d_logpd_all : nullptr, N, p->env->rew_xref, c.temp_sample,
                      c.update_method == 0 ? 1 : 0, p->d_weights, d_rew_mean);
   HIP_TRY(hipGetLastError());
@@ -577,7 +577,8 @@ extern "C" int mbd_plan_score_update(mbd_plan* p, int i, const uint32_t key_samp
     hipLaunchKernelGGL(cem_select_kernel, dim3(1), b64, sizeof(float) * (size_t)N, s, p->d_weights, N, K, p->d_idx);
     hipLaunchKernelGGL(cem_mean_kernel, ge, b64, 0, s, p->d_idx, K, p->d_Y0s, HNu, d_Ybar_im1);
   } else {  // MBD (:128-133), mppi (:33-36), cma-es (:39-45)
-    hipLaunchKernelGGL(wmean_kernel, ge, b64, 0, s, p->d_weights, p->d_Y0s, N, HNu, d_Ybar_i, p->alphas[i],
+    hipLaunchKernelGGL(wmean_kernel, dim3((HNu + kWmE - 1) / kWmE), dim3(kWmE * kWmG), 0, s, p->d_weights,
+                       p->d_Y0s, N, HNu, d_Ybar_i, p->alphas[i],
                        p->alphas_bar[i], p->alphas_bar[i - 1], c.update_method == 0 ? c.literal_score : 0, d_Ybar_im1);
     if (c.update_method == 2) {
       hipLaunchKernelGGL(cma_spread_kernel, ge, b64, 0, s, p->d_weights, p->d_Y0s, N, HNu, d_Ybar_i, p->d_spread);

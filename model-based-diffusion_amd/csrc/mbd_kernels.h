@@ -829,8 +829,8 @@ __global__ __launch_bounds__(64) void logpd_car2d_kernel(const float* __restrict
 }
 
 // ---- A4-A6: standardise, demo blend, softmax -> weights[N] (mbd_planner.py:110-127) -------------------
-// ONE wavefront. The canonical reduction order of the numerical contract: lane j accumulates the
-// elements i = j, j+64, ... in increasing i, then a xor-butterfly over the 64 lanes.
+// The canonical one-wavefront reduction of the numerical contract: lane j accumulates the elements
+// i = j, j+64, ... in increasing i, then a xor-butterfly over the 64 lanes.
 __device__ __forceinline__ float wave_sum(float x) {
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) x = x + __shfl_xor(x, off, 64);
@@ -841,86 +841,122 @@ __device__ __forceinline__ float wave_max(float x) {
   for (int off = 32; off >= 1; off >>= 1) x = fmax_(x, __shfl_xor(x, off, 64));
   return x;
 }
+// ONE 1024-thread workgroup.  Reduction order of the contract ("sumB"): thread t accumulates
+// i = t, t+1024, ... in increasing i; each wavefront runs the xor-butterfly; the 16 wavefront sums are added
+// sequentially in wavefront order (every thread does that same sum from LDS).
+constexpr int kScoreThreads = 1024;
+__device__ __forceinline__ float block_sum(float x, float* red) {
+  x = wave_sum(x);
+  __syncthreads();  // red[] may still be read from the previous reduction
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+  __syncthreads();
+  float s = red[0];
+#pragma unroll
+  for (int w = 1; w < kScoreThreads / 64; ++w) s = s + red[w];
+  return s;
+}
+__device__ __forceinline__ float block_max(float x, float* red) {
+  x = wave_max(x);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = x;
+  __syncthreads();
+  float s = red[0];
+#pragma unroll
+  for (int w = 1; w < kScoreThreads / 64; ++w) s = fmax_(s, red[w]);
+  return s;
+}
 
-__global__ __launch_bounds__(64) void score_kernel(const float* __restrict__ rews,
-                                                   const float* __restrict__ lp_demo, int N, float rew_xref,
-                                                   float temp, int std_guard, float* __restrict__ weights,
-                                                   float* __restrict__ rew_mean_out) {
+__global__ __launch_bounds__(kScoreThreads) void score_kernel(const float* __restrict__ rews,
+                                                              const float* __restrict__ lp_demo, int N,
+                                                              float rew_xref, float temp, int std_guard,
+                                                              float* __restrict__ weights,
+                                                              float* __restrict__ rew_mean_out) {
   extern __shared__ __attribute__((aligned(16))) float lg[];  // logp0 [N]
-  const int lane = threadIdx.x;
+  __shared__ float red[kScoreThreads / 64];
+  const int tid = threadIdx.x;
   float part = 0.0f;
-  for (int i = lane; i < N; i += 64) part = part + rews[i];
-  const float rew_mean = wave_sum(part) / (float)N;
+  for (int i = tid; i < N; i += kScoreThreads) part = part + rews[i];
+  const float rew_mean = block_sum(part, red) / (float)N;
   part = 0.0f;
-  for (int i = lane; i < N; i += 64) {
+  for (int i = tid; i < N; i += kScoreThreads) {
     float d = rews[i] - rew_mean;
     part = ffma(d, d, part);
   }
-  float rew_std = fsqrt(wave_sum(part) / (float)N);
+  float rew_std = fsqrt(block_sum(part, red) / (float)N);
   rew_std = (std_guard && rew_std < 1e-4f) ? 1.0f : rew_std;  // mbd_planner.py:112; path_integral.py:123 has none
-  for (int i = lane; i < N; i += 64) lg[i] = ((rews[i] - rew_mean) / rew_std) / temp;
-  if (lp_demo) {
+  for (int i = tid; i < N; i += kScoreThreads) lg[i] = ((rews[i] - rew_mean) / rew_std) / temp;
+  if (lp_demo) {  // (each thread only ever touches its own lg[i]: no barrier needed around them)
     float mx = -__builtin_inff();
-    for (int i = lane; i < N; i += 64) mx = fmax_(mx, lp_demo[i]);
-    mx = wave_max(mx);
+    for (int i = tid; i < N; i += kScoreThreads) mx = fmax_(mx, lp_demo[i]);
+    mx = block_max(mx, red);
     part = 0.0f;
-    for (int i = lane; i < N; i += 64) {
+    for (int i = tid; i < N; i += kScoreThreads) {
       float lpd = ((((lp_demo[i] - mx) + rew_xref) - rew_mean) / rew_std) / temp;
       float v = lpd > lg[i] ? lpd : lg[i];
       lg[i] = v;
       part = part + v;
     }
-    const float m = wave_sum(part) / (float)N;
+    const float m = block_sum(part, red) / (float)N;
     part = 0.0f;
-    for (int i = lane; i < N; i += 64) {
+    for (int i = tid; i < N; i += kScoreThreads) {
       float d = lg[i] - m;
       part = ffma(d, d, part);
     }
-    const float sd = fsqrt(wave_sum(part) / (float)N);
-    for (int i = lane; i < N; i += 64) lg[i] = ((lg[i] - m) / sd) / temp;
+    const float sd = fsqrt(block_sum(part, red) / (float)N);
+    for (int i = tid; i < N; i += kScoreThreads) lg[i] = ((lg[i] - m) / sd) / temp;
   }
   float mx = -__builtin_inff();
-  for (int i = lane; i < N; i += 64) mx = fmax_(mx, lg[i]);
-  mx = wave_max(mx);
+  for (int i = tid; i < N; i += kScoreThreads) mx = fmax_(mx, lg[i]);
+  mx = block_max(mx, red);
   part = 0.0f;
-  for (int i = lane; i < N; i += 64) {
+  for (int i = tid; i < N; i += kScoreThreads) {
     float e = exp_(lg[i] - mx);
     lg[i] = e;
     part = part + e;
   }
-  const float den = wave_sum(part);
-  for (int i = lane; i < N; i += 64) weights[i] = lg[i] / den;
-  if (lane == 0) *rew_mean_out = rew_mean;
+  const float den = block_sum(part, red);
+  for (int i = tid; i < N; i += kScoreThreads) weights[i] = lg[i] / den;
+  if (tid == 0) *rew_mean_out = rew_mean;
 }
 
 // ---- A7-A8: weighted mean + score update (mbd_planner.py:128-133) ---------------------------------------
-// one thread per output element e of [H][Nu]; sequential fma over n (coalesced across e)
-__global__ __launch_bounds__(64) void wmean_kernel(const float* __restrict__ weights,
-                                                   const float* __restrict__ Y0s, int N, int HNu,
-                                                   const float* __restrict__ Ybar_i, float alpha_i,
-                                                   float alpha_bar_i, float alpha_bar_im1, int literal,
-                                                   float* __restrict__ Ybar_im1) {
-  const int e = blockIdx.x * 64 + threadIdx.x;
-  if (e >= HNu) return;
-  // sequential fma over n (the canonical order); loads are independent of the accumulator, so keep 32 of
-  // them in flight per lane to cover the L2/HBM latency of the 3.5 MB stream
-  float acc = 0.0f;
+// A workgroup owns kWmE = 16 consecutive outputs e of [H][Nu] and splits the candidates into 64 groups:
+// thread (g, j) runs a sequential fma over n = g, g+64, ... for output j (a wavefront reads four 64-byte row
+// segments per load instruction); the 64 partials of an output are then added sequentially in g
+// ("wsum64" of the contract).  ceil(HNu/16) workgroups of 1024 threads: every load of a thread is in flight at once.
+constexpr int kWmE = 16, kWmG = 64;
+__global__ __launch_bounds__(kWmE * kWmG) void wmean_kernel(const float* __restrict__ weights,
+                                                            const float* __restrict__ Y0s, int N, int HNu,
+                                                            const float* __restrict__ Ybar_i, float alpha_i,
+                                                            float alpha_bar_i, float alpha_bar_im1, int literal,
+                                                            float* __restrict__ Ybar_im1) {
+  __shared__ float red[kWmG][kWmE + 1];
+  const int j = threadIdx.x & (kWmE - 1), g = threadIdx.x / kWmE;
+  const int e_raw = blockIdx.x * kWmE + j;
+  const int e = e_raw < HNu ? e_raw : HNu - 1;
   const float* __restrict__ col = Y0s + e;
-  int n = 0;
-  for (; n + 32 <= N; n += 32) {
-    float y[32];
+  float acc = 0.0f;
+  int n = g;
+  for (; n + 15 * kWmG < N; n += 16 * kWmG) {
+    float y[16], wv[16];
 #pragma unroll
-    for (int k = 0; k < 32; ++k) y[k] = col[(size_t)(n + k) * HNu];
+    for (int k = 0; k < 16; ++k) { y[k] = col[(size_t)(n + k * kWmG) * HNu]; wv[k] = weights[n + k * kWmG]; }
 #pragma unroll
-    for (int k = 0; k < 32; ++k) acc = ffma(weights[n + k], y[k], acc);
+    for (int k = 0; k < 16; ++k) acc = ffma(wv[k], y[k], acc);
   }
-  for (; n < N; ++n) acc = ffma(weights[n], col[(size_t)n * HNu], acc);
-  float out = acc;
+  for (; n < N; n += kWmG) acc = ffma(weights[n], col[(size_t)n * HNu], acc);
+  red[g][j] = acc;
+  __syncthreads();
+  if (g != 0 || e_raw >= HNu) return;
+  float tot = red[0][j];
+#pragma unroll 8
+  for (int k = 1; k < kWmG; ++k) tot = tot + red[k][j];
+  float out = tot;
   if (literal) {
     const float sab = fsqrt(alpha_bar_i);
     float Yi = Ybar_i[e] * sab;
     float t1 = 1.0f / (1.0f - alpha_bar_i);
-    float t2 = sab * acc;
+    float t2 = sab * tot;
     float score = t1 * (-Yi + t2);
     float t3 = (1.0f - alpha_bar_i) * score;
     float Yim1 = (1.0f / fsqrt(alpha_i)) * (Yi + t3);

@@ -202,24 +202,49 @@ ORC_API void orc_sample(const uint32_t key_sample[2], int impl, int N, int HNu, 
 /* score estimate  (mbd_planner.py:110-135)                                                          */
 /*   rews[N] (= mean_H rewss), optional demo log-densities lp[N], Y0s[N][HNu], Ybar_i[HNu]           */
 /*   -> weights[N], Ybar_im1[HNu], returns rews.mean()                                                */
-/* reductions are sequential f32 sums in index order (XLA uses tree reductions: last-bit             */
-/* differences expected).                                                              */
+/* reductions follow the fixed orders below (XLA uses its own tree reductions: last-bit differences  */
+/* expected).                                                                          */
 /* ------------------------------------------------------------------------------------------------ */
-/* canonical reductions (spec_math.h): 64 strided partials + xor-butterfly */
+/* canonical reductions (spec_math.h).
+ *   sum_f32:  one wavefront — 64 strided partials + xor-butterfly (cma-es sigma, orc_sp_sum)
+ *   sumB / sumsq_devB:  one 1024-thread workgroup, the order of the score kernel — partial t accumulates
+ *     i = t, t+1024, ... in increasing i; each wavefront (64 consecutive t) runs the xor-butterfly; the 16
+ *     wavefront sums are then added sequentially in wavefront order
+ *   wsum64: the weighted mean over candidates — 64 partials, partial g is a sequential fma over
+ *     n = g, g+64, ... in increasing n; the 64 partials are then added sequentially in g               */
 static float sum_f32(const float* x, int n) {
   float part[64];
   for (int j = 0; j < 64; ++j) part[j] = 0.0f;
   for (int i = 0; i < n; ++i) part[i & 63] = part[i & 63] + x[i];
   return sp_reduce_sum64(part);
 }
-static float sumsq_dev_f32(const float* x, int n, float mean) {
-  float part[64];
-  for (int j = 0; j < 64; ++j) part[j] = 0.0f;
+static float reduceB(const float* part /* [1024] */) {
+  float s = sp_reduce_sum64(part);
+  for (int w = 1; w < 16; ++w) s = s + sp_reduce_sum64(part + 64 * w);
+  return s;
+}
+static float sumB(const float* x, int n) {
+  float part[1024];
+  for (int j = 0; j < 1024; ++j) part[j] = 0.0f;
+  for (int i = 0; i < n; ++i) part[i & 1023] = part[i & 1023] + x[i];
+  return reduceB(part);
+}
+static float sumsq_devB(const float* x, int n, float mean) {
+  float part[1024];
+  for (int j = 0; j < 1024; ++j) part[j] = 0.0f;
   for (int i = 0; i < n; ++i) {
     float d = x[i] - mean;
-    part[i & 63] = __builtin_fmaf(d, d, part[i & 63]);
+    part[i & 1023] = __builtin_fmaf(d, d, part[i & 1023]);
   }
-  return sp_reduce_sum64(part);
+  return reduceB(part);
+}
+static float wsum64(const float* weights, const float* col /* stride HNu */, int N, int HNu) {
+  float part[64];
+  for (int g = 0; g < 64; ++g) part[g] = 0.0f;
+  for (int n = 0; n < N; ++n) part[n & 63] = __builtin_fmaf(weights[n], col[(size_t)n * HNu], part[n & 63]);
+  float s = part[0];
+  for (int g = 1; g < 64; ++g) s = s + part[g];
+  return s;
 }
 static float max_f32(const float* x, int n) {
   float m = x[0];
@@ -232,8 +257,8 @@ ORC_API float orc_score_update(int N, int HNu, const float* rews, const float* l
                                float alpha_i, float alpha_bar_i, float alpha_bar_im1, int literal,
                                float* weights /* [N] */, float* Ybar_im1 /* [HNu] */) {
   float* logp0 = (float*)malloc(sizeof(float) * (size_t)N);
-  float rew_mean = sum_f32(rews, N) / (float)N;                                   /* :113 */
-  float rew_std = __builtin_sqrtf(sumsq_dev_f32(rews, N, rew_mean) / (float)N);   /* :111 (ddof 0) */
+  float rew_mean = sumB(rews, N) / (float)N;                                   /* :113 */
+  float rew_std = __builtin_sqrtf(sumsq_devB(rews, N, rew_mean) / (float)N);   /* :111 (ddof 0) */
   if (rew_std < 1e-4f) rew_std = 1.0f;                                            /* :112 */
   for (int n = 0; n < N; ++n) logp0[n] = ((rews[n] - rew_mean) / rew_std) / temp; /* :114 */
   if (lp_demo) {                                                                  /* :117-125 */
@@ -242,21 +267,19 @@ ORC_API float orc_score_update(int N, int HNu, const float* rews, const float* l
       float lpd = ((((lp_demo[n] - mx) + rew_xref) - rew_mean) / rew_std) / temp;
       if (lpd > logp0[n]) logp0[n] = lpd;
     }
-    float m = sum_f32(logp0, N) / (float)N;
-    float sd = __builtin_sqrtf(sumsq_dev_f32(logp0, N, m) / (float)N);
+    float m = sumB(logp0, N) / (float)N;
+    float sd = __builtin_sqrtf(sumsq_devB(logp0, N, m) / (float)N);
     for (int n = 0; n < N; ++n) logp0[n] = ((logp0[n] - m) / sd) / temp; /* no zero-std guard (:125) */
   }
   /* jax.nn.softmax (:127) */
   float mx = max_f32(logp0, N);
   for (int n = 0; n < N; ++n) weights[n] = sp_exp_f32(logp0[n] - mx);
-  float den = sum_f32(weights, N);
+  float den = sumB(weights, N);
   for (int n = 0; n < N; ++n) weights[n] = weights[n] / den;
-  /* Ybar = einsum("n,nij->ij") (:128): sequential fma over n */
+  /* Ybar = einsum("n,nij->ij") (:128): wsum64 order */
   const float sab = __builtin_sqrtf(alpha_bar_i);
   for (int e = 0; e < HNu; ++e) {
-    float acc = 0.0f;
-    for (int n = 0; n < N; ++n) acc = __builtin_fmaf(weights[n], Y0s[(size_t)n * HNu + e], acc);
-    float Ybar = acc;
+    float Ybar = wsum64(weights, Y0s + e, N, HNu);
     if (literal) { /* :100,130-133 */
       float Yi = Ybar_i[e] * sab;
       float t1 = 1.0f / (1.0f - alpha_bar_i);
@@ -417,12 +440,12 @@ ORC_API float orc_sp_sum(const float* x, int n) { return sum_f32(x, n); }
 ORC_API float orc_pi_update(int method, int N, int HNu, const float* rews, float temp, const float* Y0s,
                             const float* mu_t, float* sigma_inout, float* weights, float* mu_tm1) {
   float* logp0 = (float*)malloc(sizeof(float) * (size_t)N);
-  float rew_mean = sum_f32(rews, N) / (float)N;
-  float rew_std = __builtin_sqrtf(sumsq_dev_f32(rews, N, rew_mean) / (float)N);
+  float rew_mean = sumB(rews, N) / (float)N;
+  float rew_std = __builtin_sqrtf(sumsq_devB(rews, N, rew_mean) / (float)N);
   for (int n = 0; n < N; ++n) logp0[n] = ((rews[n] - rew_mean) / rew_std) / temp;
   float mx = max_f32(logp0, N);
   for (int n = 0; n < N; ++n) weights[n] = sp_exp_f32(logp0[n] - mx);
-  float den = sum_f32(weights, N);
+  float den = sumB(weights, N);
   for (int n = 0; n < N; ++n) weights[n] = weights[n] / den;
   if (method == 3) { /* argsort(weights)[::-1][:10]: ties resolved towards the HIGHER index */
     int K = N < 10 ? N : 10;
@@ -442,11 +465,7 @@ ORC_API float orc_pi_update(int method, int N, int HNu, const float* rews, float
     }
     free(used);
   } else {
-    for (int e = 0; e < HNu; ++e) {
-      float acc = 0.0f;
-      for (int n = 0; n < N; ++n) acc = __builtin_fmaf(weights[n], Y0s[(size_t)n * HNu + e], acc);
-      mu_tm1[e] = acc;
-    }
+    for (int e = 0; e < HNu; ++e) mu_tm1[e] = wsum64(weights, Y0s + e, N, HNu);
     if (method == 2) {
       float* s = (float*)malloc(sizeof(float) * (size_t)HNu);
       for (int e = 0; e < HNu; ++e) {
