@@ -240,8 +240,9 @@ static inline float sp_log1p_f32(float t) {
   return sp_log_f32(u) * (t / (u - 1.0f));
 }
 
-/* canonical f32 reduction over n elements: 64 strided partials (element i goes to partial i%64, in
- * increasing i), then a xor-butterfly 32,16,8,4,2,1 — exactly what one wavefront does. */
+/* canonical f32 reduction over n elements by ONE wavefront: 64 strided partials (element i goes to partial
+ * i%64, in increasing i), then a xor-butterfly 32,16,8,4,2,1.  (The score kernel's workgroup-wide order —
+ * 16 of these, added sequentially — and the weighted mean's 64-partial order are in mbd_oracle_core.c.) */
 static inline float sp_reduce_sum64(const float* partial) {
   float a[64], b[64];
   memcpy(a, partial, sizeof(a));
