@@ -40,8 +40,17 @@ struct RolloutParams {
 };
 
 __device__ __forceinline__ float shfl(float v, int src) { return __shfl(v, src, 64); }
-// one full LDS-counter wait after a batch of shuffles instead of a partial s_waitcnt before every consumer
-__device__ __forceinline__ void shfl_join() { __builtin_amdgcn_s_waitcnt(0xC07F); }
+// One full LDS-counter wait after a batch of shuffles instead of a partial s_waitcnt before every consumer
+// (with one wavefront per SIMD every s_waitcnt costs a 4-cycle issue slot).  ds_bpermute is not a memory
+// operation to the machine scheduler, so without the two scheduling barriers it moves shuffles across the wait.
+__device__ __forceinline__ void shfl_join() {
+  __builtin_amdgcn_sched_barrier(0);
+  __builtin_amdgcn_s_waitcnt(0xC07F);
+  __builtin_amdgcn_sched_barrier(0);
+}
+// "issue what was requested so far, now": keeps the scheduler from sinking a batch of shuffles towards its
+// consumers, so that the LDS round trip overlaps the independent work that follows in program order
+__device__ __forceinline__ void shfl_issue() { __builtin_amdgcn_sched_barrier(0); }
 __device__ __forceinline__ v3 shfl3(v3 v, int src) { return v3{shfl(v.x, src), shfl(v.y, src), shfl(v.z, src)}; }
 __device__ __forceinline__ q4 shfl4(q4 q, int src) {
   return q4{shfl(q.w, src), shfl(q.x, src), shfl(q.y, src), shfl(q.z, src)};
@@ -378,6 +387,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
     for (int fr = 0; fr < nfr; ++fr) {
       // ---- (1) joints.acceleration_update ----------------------------------------------------------
       v3 Pv = shfl3(v, plane), Pw = shfl3(w, plane);
+      shfl_issue();  // in flight across the joint frames, joined before the anchor velocities
       v3 Pp = Pp_next;  // (no join here: the velocities are first needed after the joint frames)
       q4 Pr = Pr_next;
       // a link hanging off the world sees the static identity frame. Only models with a jointed root need
@@ -391,6 +401,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         JointFrames f = joint_frames(jc, Pp, Pr, p, r);
         const WInert2<ISO> W2 = world_inertia2<ISO>(ip, ic, pack4(Pr, r));
         const v3x2 arm = sub2(f.anchor, pack3(Pp, p));                 // (rp, rc)
+        shfl_join();
         const v3x2 va = add2(pack3(Pv, v), cross2(pack3(Pw, w), arm));  // anchor velocities (vp, vc)
         v3 rel_v = sub(hi3(va), lo3(va)), rel_w = sub(w, Pw);
         v3 T = mk3(0, 0, 0), F = mk3(0, 0, 0);
@@ -456,6 +467,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       shfl_join();
       if constexpr (SLIDES) { Pp = sel3(world_parent, mk3(0, 0, 0), Pp); Pr = sel4(world_parent, q4{1, 0, 0, 0}, Pr); }
       v3 dc_p, dc_th, dp_p, dp_th;
+      v3 cp[MAXCH], cth[MAXCH];
       {
         JointFrames f = joint_frames(jc, Pp, Pr, p, r);
         v3 d = sub(f.ap, f.ac);
@@ -513,6 +525,14 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
             dth2 = add2(dth2, scale2(iinv2<ISO>(ip, ic, W2, cross2(arm, Ps2)), mk2(-1.0f, 1.0f)));
           }
         }
+        // the translational corrections are final: the parent's share leaves now and its round trip hides
+        // behind the angular limit corrections
+        dc_p = hi3(lin2); dp_p = lo3(lin2);
+#pragma unroll
+        for (int c = 0; c < MAXCH; ++c) {
+          if (child_slot(c)) cp[c] = shfl3(dp_p, child_src[c]);
+        }
+        shfl_issue();
         ang_apply(ca, q_ta.y, js_ang, dth2);
         // joint limits on the Euler angles: three corrections, quotients (0,1) packed, 2 alone
         auto viol_of = [&](int k, float a) {  // both differences first: selects, not branches
@@ -528,15 +548,13 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         ang_apply(c0, q01.x, js_ang, dth2);
         ang_apply(c1, q01.y, js_ang, dth2);
         ang_apply(c2_, q2, js_ang, dth2);
-        dc_p = hi3(lin2); dp_p = lo3(lin2);
         dc_th = hi3(dth2); dp_th = lo3(dth2);
       }
       {
         v3x2 acc = pack3(dc_p, dc_th);  // (translation, rotation vector), packed
-        v3 cp[MAXCH], cth[MAXCH];
 #pragma unroll
         for (int c = 0; c < MAXCH; ++c) {
-          if (child_slot(c)) { cp[c] = shfl3(dp_p, child_src[c]); cth[c] = shfl3(dp_th, child_src[c]); }
+          if (child_slot(c)) cth[c] = shfl3(dp_th, child_src[c]);
         }
         shfl_join();
 #pragma unroll
@@ -593,6 +611,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         r = qrotvec(r, cd_th);
         Pp_next = shfl3(p, plane);  // consumed by stage (1) of the next substep
         Pr_next = shfl4(r, plane);
+        shfl_issue();  // the round trip hides behind stages (5) and (6)
       }
       // ---- (5) integrator.project_xd ------------------------------------------------------------------
       const v3 v_old = v, w_old = w;
