@@ -214,6 +214,20 @@ __device__ __forceinline__ void ang_apply(const AngPrep& a, float quot, float sc
 }
 // contact normal = +z of the floor plane
 __device__ __forceinline__ v3 crossz(v3 a) { return v3{a.y, -a.x, 0.0f}; }
+// the same for vectors whose z component is an exact zero: value-identical to the generic helpers, minus the
+// products with that zero
+__device__ __forceinline__ float dot_az0(v3 a, v3 b) { return ffma(a.x, b.x, a.y * b.y); }
+__device__ __forceinline__ v3 cross_bz0(v3 a, v3 b) {
+  return v3{-(a.z * b.y), a.z * b.x, ffma(a.x, b.y, -(a.y * b.x))};
+}
+template <bool ISO>
+__device__ __forceinline__ v3 iinv_z0(const Inert<ISO>& in, const WInert<ISO>& W, v3 v) {
+  if constexpr (ISO) {
+    return v3{v.x * in.ib[0], v.y * in.ib[0], 0.0f};
+  } else {
+    return v3{ffma(W.w[3], v.y, W.w[0] * v.x), ffma(W.w[1], v.y, W.w[3] * v.x), ffma(W.w[5], v.y, W.w[4] * v.x)};
+  }
+}
 
 // LPS   lanes per candidate (power of two >= n_links)
 // ISO   model-wide isotropic inverse inertia (spring_inertia_scale = 1 models: the humanoid)
@@ -584,15 +598,15 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           v3 pos = mk3(ctr.x, ctr.y, ctr.z - ffma(-0.5f, pen, col_rad[j]));
           v3 rc = sub(pos, p);
           v3 cn = crossz(rc);
-          v3 icn = iinv<ISO>(ic, Wc, cn);
-          float wn = ic.inv_mass + dot(cn, icn);
+          v3 icn = iinv_z0<ISO>(ic, Wc, cn);
+          float wn = ic.inv_mass + dot_az0(cn, icn);
           // (dlam and gt share one packed division below)
           v3 rl = irot(rc, r);
           v3 pprev = add(p_prev, rot(rl, r_prev));
           v3 dx = sub(pos, pprev);
           dx.z = 0.0f;
           float ct2 = ffma(dx.x, dx.x, dx.y * dx.y);
-          v3 cnt = cross(rc, dx);
+          v3 cnt = cross_bz0(rc, dx);
           v3 icnt = iinv<ISO>(ic, Wc, cnt);
           float dent = ffma(ic.inv_mass, ct2, dot(cnt, icnt));
           const f2 q_ng = div2_(mk2(pen, ct2), mk2(wn, dent + 1e-20f));
@@ -600,9 +614,13 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           float gt = q_ng.y;
           v3 Pimp = mk3(0.0f, 0.0f, dlam);
           float lim = mu * dlam;
-          Pimp = sel3((ct2 * gt) * gt < lim * lim, axpy(-gt, dx, Pimp), Pimp);
-          v3 ncd_p = axpy(ic.inv_mass, Pimp, cd_p);
-          v3 ncd_th = add(cd_th, iinv<ISO>(ic, Wc, cross(rc, Pimp)));
+          const bool stick = (ct2 * gt) * gt < lim * lim;
+          Pimp.x = stick ? (-gt) * dx.x : 0.0f;
+          Pimp.y = stick ? (-gt) * dx.y : 0.0f;
+          const v3 dth = iinv<ISO>(ic, Wc, cross(rc, Pimp));
+          // (the first collider adds to exact zeros: skipped)
+          v3 ncd_p = j == 0 ? scale(Pimp, ic.inv_mass) : axpy(ic.inv_mass, Pimp, cd_p);
+          v3 ncd_th = j == 0 ? dth : add(cd_th, dth);
           cd_p = sel3(active, ncd_p, cd_p);
           cd_th = sel3(active, ncd_th, cd_th);
           con_pos[j] = pos; con_dlam[j] = dlam; con_act[j] = active;
@@ -635,18 +653,17 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         v3 vt = mk3(vpt.x, vpt.y, 0.0f);
         float vtn = fsqrt(ffma(vt.x, vt.x, vt.y * vt.y));
         float inv = div_(1.0f, vtn + 1e-10f);
-        v3 dir = scale(vt, inv);
-        v3 cn = crossz(rc), cdv = cross(rc, dir);
-        v3 icn = iinv<ISO>(ic, Wc, cn), icd = iinv<ISO>(ic, Wc, cdv);
-        float wn = ic.inv_mass + dot(cn, icn), wt = ic.inv_mass + dot(cdv, icd);
+        v3 dir = mk3(vt.x * inv, vt.y * inv, 0.0f);
+        v3 cn = crossz(rc), cdv = cross_bz0(rc, dir);
+        v3 icn = iinv_z0<ISO>(ic, Wc, cn), icd = iinv<ISO>(ic, Wc, cdv);
+        float wn = ic.inv_mass + dot_az0(cn, icn), wt = ic.inv_mass + dot(cdv, icd);
         float rest = -elast * vn_prev;
         float dvn = fmin_(rest, 0.0f) - vn;
         float jt_max = (mu * con_dlam[j]) * inv_dt;
         float dvt = fmin_(jt_max * wt, vtn);
         const f2 q_nt = div2_(mk2(dvn, dvt), mk2(wn, wt));
         float jn = q_nt.x, jt = -q_nt.y;
-        v3 Pimp = scale(dir, jt);
-        Pimp.z = Pimp.z + jn;
+        v3 Pimp = mk3(dir.x * jt, dir.y * jt, jn);
         v3 nv = axpy(ic.inv_mass, Pimp, v);
         v3 nw = add(w, iinv<ISO>(ic, Wc, cross(rc, Pimp)));
         v = sel3(con_act[j], nv, v);

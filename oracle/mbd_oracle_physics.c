@@ -137,6 +137,20 @@ static void ang_correct(const real e[3], const inert_t* ip, const inert_t* ic, r
 /* the contact normal is the +z axis of the floor plane: specialised vector helpers (same roundings
  * as the generic ones with n = (0,0,1), minus the multiplications by zero) */
 static inline void crossz(const real a[3], real o[3]) { o[0] = a[1]; o[1] = -a[0]; o[2] = R(0); }
+/* the same for vectors whose z component is an exact zero (contact normals' moment arms, tangential slip):
+ * value-identical to the generic helpers, minus the products with that zero */
+static inline real dot_az0(const real a[3], const real b[3]) { return sp_fma(a[0], b[0], a[1] * b[1]); }
+static inline void cross_bz0(const real a[3], const real b[3], real o[3]) {
+  real x = -(a[2] * b[1]), y = a[2] * b[0], z = sp_fma(a[0], b[1], -(a[1] * b[0]));
+  o[0] = x; o[1] = y; o[2] = z;
+}
+static inline void iinv_apply_z0(const inert_t* in, const real v[3], real o[3]) {
+  if (in->world) { sp_set3(o, 0, 0, 0); return; }
+  if (in->iso) { sp_set3(o, v[0] * in->ib[0], v[1] * in->ib[0], R(0)); return; }
+  const real* W = in->W;
+  real m0 = sp_fma(W[3], v[1], W[0] * v[0]), m1 = sp_fma(W[1], v[1], W[3] * v[0]), m2 = sp_fma(W[5], v[1], W[4] * v[0]);
+  sp_set3(o, m0, m1, m2);
+}
 
 typedef struct {
   int active;
@@ -339,8 +353,8 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_set3(con[k].pos, ctr[0], ctr[1], ctr[2] - sp_fma(R(-0.5), pen, rad));
     real rc[3], cn[3], icn[3];
     sp_sub3(con[k].pos, x[l].p, rc);
-    crossz(rc, cn); iinv_apply(&in[l], cn, icn);
-    real w = in[l].inv_mass + sp_dot3(cn, icn);
+    crossz(rc, cn); iinv_apply_z0(&in[l], cn, icn);
+    real w = in[l].inv_mass + dot_az0(cn, icn);
     real dlam = sp_div(pen, w) * R(m->collide_scale);
     con[k].dlam = dlam;
     real Pimp[3] = {0, 0, dlam}, mom[3];
@@ -354,11 +368,11 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     dx[2] = R(0);
     real ct2 = sp_fma(dx[0], dx[0], dx[1] * dx[1]);
     real cnt[3], icnt[3];
-    sp_cross3(rc, dx, cnt); iinv_apply(&in[l], cnt, icnt);
+    cross_bz0(rc, dx, cnt); iinv_apply(&in[l], cnt, icnt);
     real dent = sp_fma(in[l].inv_mass, ct2, sp_dot3(cnt, icnt));
     real gt = sp_div(ct2, dent + R(1e-20));
     real lim = mu * dlam;
-    if ((ct2 * gt) * gt < lim * lim) sp_axpy3(-gt, dx, Pimp);
+    if ((ct2 * gt) * gt < lim * lim) { Pimp[0] = (-gt) * dx[0]; Pimp[1] = (-gt) * dx[1]; }
     sp_axpy3(in[l].inv_mass, Pimp, cd_p[l]);
     sp_cross3(rc, Pimp, mom); iinv_apply(&in[l], mom, t); sp_add3(cd_th[l], t, cd_th[l]);
   }
@@ -390,18 +404,16 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     real vtn = sp_sqrt(sp_fma(vt[0], vt[0], vt[1] * vt[1]));
     real inv = sp_div(R(1), vtn + R(1e-10));
     real dir[3], cn[3], icn[3], cdv[3], icd[3];
-    sp_scale3(vt, inv, dir);
-    crossz(rc, cn); iinv_apply(&in[l], cn, icn);
-    sp_cross3(rc, dir, cdv); iinv_apply(&in[l], cdv, icd);
-    real wn = in[l].inv_mass + sp_dot3(cn, icn), wt = in[l].inv_mass + sp_dot3(cdv, icd);
+    sp_set3(dir, vt[0] * inv, vt[1] * inv, R(0));
+    crossz(rc, cn); iinv_apply_z0(&in[l], cn, icn);
+    cross_bz0(rc, dir, cdv); iinv_apply(&in[l], cdv, icd);
+    real wn = in[l].inv_mass + dot_az0(cn, icn), wt = in[l].inv_mass + sp_dot3(cdv, icd);
     real rest = -R(m->elasticity) * vn_prev;
     real dvn = sp_min(rest, R(0)) - vn;
     real jt_max = (mu * con[k].dlam) * inv_dt; /* friction impulse bound mu * lambda_n / h */
     real dvt = sp_min(jt_max * wt, vtn);
     real jn = sp_div(dvn, wn), jt = -sp_div(dvt, wt);
-    real Pimp[3];
-    sp_scale3(dir, jt, Pimp);
-    Pimp[2] = Pimp[2] + jn;
+    real Pimp[3] = {dir[0] * jt, dir[1] * jt, jn};
     sp_axpy3(in[l].inv_mass, Pimp, xd[l].v);
     real mom[3];
     sp_cross3(rc, Pimp, mom); iinv_apply(&in[l], mom, t); sp_add3(xd[l].w, t, xd[l].w);
