@@ -163,6 +163,57 @@ def _one_step(gpu, orc, name, N, H, Nd, temp, impl, demo, i=None):
     plan.close()
 
 
+@pytest.mark.parametrize("name,H,demo", [("car2d", 7, False), ("car2d", 50, True), ("hopper", 11, False)])
+@pytest.mark.parametrize("N", [1, 3, 63, 64, 65, 1000, 1024, 1025, 2500, 5003])
+def test_score_update_ragged_sizes(gpu, orc, name, H, demo, N):
+    """mbd_plan_score_update on its own, at candidate counts around every boundary of its two kernels (one
+    1024-thread workgroup; 16-output x 64-group tiles): resident Y0s from the sampler, SYNTHETIC rewards (ties,
+    outliers) and demo log-densities, against the oracle bit for bit — weights, Ybar_{i-1}, mean reward."""
+    import torch
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.mbd_planner import Args, Plan
+    env = get_env(name)
+    args = Args(env_name=name, Nsample=N, Hsample=H, Ndiffuse=30, temp_sample=0.2, enable_demo=demo,
+                disable_recommended_params=True, not_render=True)
+    plan = Plan(env, args)
+    plan.set_state0(env.reset(gpu.prng_key(3)))
+    Nu, i = env.action_size, 17
+    g = np.random.default_rng(N)
+    Ybar = (g.normal(size=H * Nu) * 0.3).astype(np.float32)
+    d_Y, loc = torch.tensor(Ybar, device="cuda"), torch.zeros(N, device="cuda")
+    d_lp = torch.zeros(N, device="cuda") if demo else None
+    ks = gpu.key_array(gpu.prng_key(N + 11))
+    gpu.check(plan.lib.mbd_plan_sample_rollout(plan.h, i, ks, d_Y.data_ptr(), loc.data_ptr(),
+                                               d_lp.data_ptr() if demo else None, None))
+    torch.cuda.synchronize()
+    Y0s = plan.peek()[0]
+    a, ab, _ = plan.schedule()
+    for case in range(3):
+        rews = g.normal(size=N).astype(np.float32)
+        if case == 1:
+            rews[:] = np.float32(0.25)  # zero spread: the 1e-4 guard (mbd_planner.py:112)
+        if case == 2 and N > 2:
+            rews[N // 2] = 40.0
+            rews[: N // 3] = rews[0]
+        lp = (g.normal(size=N) * 3 - 2).astype(np.float32) if demo else None
+        if demo and case == 1:
+            continue  # a constant logp0 blend has zero spread and no guard at :125 (NaN in the reference too)
+        d_r = torch.tensor(rews, device="cuda")
+        d_l = torch.tensor(lp, device="cuda") if demo else None
+        out, rm = torch.zeros(H * Nu, device="cuda"), torch.zeros(1, device="cuda")
+        gpu.check(plan.lib.mbd_plan_score_update(plan.h, i, ks, d_Y.data_ptr(), d_r.data_ptr(),
+                                                 d_l.data_ptr() if demo else None, out.data_ptr(), rm.data_ptr(), None))
+        torch.cuda.synchronize()
+        ref, w_ref, m_ref = orc.score_update(rews, Y0s, Ybar, float(a[i]), float(ab[i]), float(ab[i - 1]), 0.2,
+                                             lp_demo=lp, rew_xref=float(env.rew_xref) if demo else 0.0)
+        w = plan.peek()[2]
+        # (a single candidate with demo has zero spread at :125: NaN here, in the oracle and in the reference)
+        assert np.array_equal(w, w_ref, equal_nan=True), (N, case)
+        assert np.array_equal(out.cpu().numpy(), ref, equal_nan=True), (N, case)
+        assert np.float32(rm.item()) == np.float32(m_ref)
+    plan.close()
+
+
 @pytest.mark.parametrize("impl", [0, 1])
 def test_reverse_once_humanoidrun(gpu, orc, impl, monkeypatch):
     monkeypatch.setenv("MBD_THREEFRY_PARTITIONABLE", str(impl))
