@@ -72,6 +72,10 @@ struct mbd_env {
   int lps = 16, max_children = 0, max_col = 0;
   bool slides = false;
   bool slide_limits = false;  // any slide dof with a finite range
+  // DPP layout (kernels.h "lane exchange without the LDS"): lane <-> link tables when the tree fits the shifts
+  bool dpp_ok = false;
+  signed char lane_tab[32];
+  signed char* d_lane_tab = nullptr;
   // scratch for the single-env step path
   float *d_s_in = nullptr, *d_act = nullptr, *d_s_out = nullptr, *d_rew = nullptr;
   int state_size() const { return kind == ENV_CAR2D ? 3 : model.n_links * MBD_LINK_STATE; }
@@ -97,6 +101,38 @@ struct mbd_plan {
 
 namespace {
 
+// The DPP instantiations are built for the humanoid family's tree: lane(parent) = lane(s-th child) + kDppDs.
+// A model qualifies if some root lane puts every link on a distinct lane of the 16-lane row.
+constexpr int kDppD0 = 1, kDppD1 = -4, kDppD2 = -6;
+bool find_dpp_layout(const mbd_model_t& m, signed char tab[32]) {
+  const int D[3] = {kDppD0, kDppD1, kDppD2};
+  const int L = m.n_links;
+  if (L > 16) return false;
+  for (int root = 0; root < 16; ++root) {
+    int lane[MBD_MAX_LINKS];
+    bool used[16] = {false}, ok = true;
+    for (int l = 0; l < L && ok; ++l) {
+      if (m.parent[l] < 0) {
+        if (l != 0) { ok = false; break; }  // one tree, rooted at link 0
+        lane[l] = root;
+      } else {
+        if (m.parent[l] >= l) { ok = false; break; }
+        int slot = 0;
+        for (int c = 0; c < l; ++c) slot += m.parent[c] == m.parent[l] ? 1 : 0;
+        if (slot > 2) { ok = false; break; }
+        lane[l] = lane[m.parent[l]] - D[slot];
+      }
+      if (lane[l] < 0 || lane[l] > 15 || used[lane[l]]) { ok = false; break; }
+      used[lane[l]] = true;
+    }
+    if (!ok) continue;
+    for (int i = 0; i < 32; ++i) tab[i] = -1;
+    for (int l = 0; l < L; ++l) { tab[lane[l]] = (signed char)l; tab[16 + l] = (signed char)lane[l]; }
+    return true;
+  }
+  return false;
+}
+
 int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B, int H, float* d_rewss,
                    float* d_rews, float* d_xpos, float* d_state_final, hipStream_t stream) {
   if (B <= 0 || H <= 0) return fail(MBD_ERR_INVALID, "rollout: B=%d H=%d", B, H);
@@ -107,15 +143,20 @@ int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B
     return MBD_OK;
   }
   RolloutParams P{env->d_model, d_state0, d_us, d_rewss, d_rews, d_xpos, d_state_final, B, H,
-                  env->slide_limits ? 1 : 0, env->max_children, g_dbg_clock};
+                  env->slide_limits ? 1 : 0, env->max_children, env->d_lane_tab, g_dbg_clock};
   const bool iso = env->model.iso_inertia != 0;
   const int spw = 64 / env->lps;
   dim3 grid((B + spw - 1) / spw), block(64);
 #define MBD_LAUNCH(LPS, ISO, SL, CH, COL) \
   hipLaunchKernelGGL((rollout_kernel<LPS, ISO, SL, CH, COL>), grid, block, 0, stream, P)
-  if (env->lps == 16 && iso && !env->slides && env->max_children <= 3 && env->max_col <= 1) {
-    MBD_LAUNCH(16, true, false, 3, 1);  // the humanoid (metric config)
-  } else if (env->lps == 16 && iso && !env->slides && env->max_children <= 3 && env->max_col <= 5) {
+  const bool humanoid_shape = env->lps == 16 && iso && !env->slides && env->max_children <= 3;
+  if (humanoid_shape && env->max_col <= 1 && env->dpp_ok) {
+    hipLaunchKernelGGL((rollout_kernel<16, true, false, 3, 1, kDppD0, kDppD1, kDppD2>), grid, block, 0, stream, P);
+  } else if (humanoid_shape && env->max_col <= 5 && env->dpp_ok) {
+    hipLaunchKernelGGL((rollout_kernel<16, true, false, 3, 5, kDppD0, kDppD1, kDppD2>), grid, block, 0, stream, P);
+  } else if (humanoid_shape && env->max_col <= 1) {
+    MBD_LAUNCH(16, true, false, 3, 1);  // humanoid-like trees that do not fit the DPP shifts
+  } else if (humanoid_shape && env->max_col <= 5) {
     MBD_LAUNCH(16, true, false, 3, 5);  // humanoidstandup: up to 5 sphere colliders on one link
   } else if (env->lps == 16 && iso && !env->slides && env->max_col <= 2) {
     MBD_LAUNCH(16, true, false, 4, 2);  // ant: free root with four legs, no slide / weld joints
@@ -319,6 +360,11 @@ extern "C" int mbd_env_create_model(const char* env_name, int device, const mbd_
       return fail(MBD_ERR_UNSUPPORTED, "a link has %d sphere colliders: more than this kernel family is built for", mc);
     }
   }
+  e->dpp_ok = e->lps == 16 && find_dpp_layout(m, e->lane_tab);
+  if (!e->dpp_ok)
+    for (int i = 0; i < 32; ++i) e->lane_tab[i] = (signed char)(i & 15);  // identity (unused by the other kernels)
+  HIP_TRY(hipMalloc(&e->d_lane_tab, sizeof(e->lane_tab)));
+  HIP_TRY(hipMemcpy(e->d_lane_tab, e->lane_tab, sizeof(e->lane_tab), hipMemcpyHostToDevice));
   HIP_TRY(hipMalloc(&e->d_model, sizeof(mbd_model_t)));
   HIP_TRY(hipMemcpy(e->d_model, &e->model, sizeof(mbd_model_t), hipMemcpyHostToDevice));
   if (xref) {
@@ -338,7 +384,7 @@ extern "C" int mbd_env_create_model(const char* env_name, int device, const mbd_
 extern "C" int mbd_env_destroy(mbd_env* e) {
   if (!e) return MBD_OK;
   (void)hipSetDevice(e->device);
-  (void)hipFree(e->d_model); (void)hipFree(e->d_xref);
+  (void)hipFree(e->d_model); (void)hipFree(e->d_xref); (void)hipFree(e->d_lane_tab);
   (void)hipFree(e->d_s_in); (void)hipFree(e->d_s_out); (void)hipFree(e->d_act); (void)hipFree(e->d_rew);
   delete e;
   return MBD_OK;

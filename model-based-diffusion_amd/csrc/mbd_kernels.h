@@ -36,6 +36,9 @@ struct RolloutParams {
   int B, H;
   int slide_limits;  // any slide dof with a finite range (wave-uniform: the limit corrections are skipped otherwise)
   int max_children;  // largest child count in the model (wave-uniform bound of the generic kernels' child loops)
+  // DPP instantiations only: lane (within the 16-lane row) <-> link tables, [0..15] lane -> link (-1: padding),
+  // [16..31] link -> lane.  Device memory, written by the host when the model's tree fits the shift pattern.
+  const signed char* lane_tab;
   unsigned long long* dbg_clock;  // nullptr, or [grid][3] = (start tick, end tick, HW_ID|XCC<<32) (tools/probes)
 };
 
@@ -54,6 +57,30 @@ __device__ __forceinline__ void shfl_issue() { __builtin_amdgcn_sched_barrier(0)
 __device__ __forceinline__ v3 shfl3(v3 v, int src) { return v3{shfl(v.x, src), shfl(v.y, src), shfl(v.z, src)}; }
 __device__ __forceinline__ q4 shfl4(q4 q, int src) {
   return q4{shfl(q.w, src), shfl(q.x, src), shfl(q.y, src), shfl(q.z, src)};
+}
+
+// ---- lane exchange without the LDS: DPP row shifts --------------------------------------------------------
+// A candidate occupies one 16-lane DPP row.  When the link tree can be laid out so that every s-th child (in link
+// order) sits at lane(parent) - DS for a fixed shift DS per slot s, parent<->child traffic is a row shift executed
+// by the VALU (v_mul_f32_dpp): no LDS issue slots (a ds_bpermute_b32 costs two), no round trip to wait for.
+// dpp_from<K>(x): the value of x in lane i+K of the same row (0 when that lane is outside the row).
+template <int K>
+__device__ __forceinline__ float dpp_from(float x) {
+  static_assert(K != 0 && K > -16 && K < 16, "row shift");
+  constexpr int ctrl = K > 0 ? 0x100 + K /* row_shl:K */ : 0x110 - K /* row_shr:-K */;
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true));
+}
+// select-by-mask sum over the three slots: exactly one mask is 1.0f (or none): products and sums are exact
+template <int K0, int K1, int K2>
+__device__ __forceinline__ float dpp_pick(float x, float m0, float m1, float m2) {
+  float r = dpp_from<K0>(x) * m0;
+  r = ffma(dpp_from<K1>(x), m1, r);
+  return ffma(dpp_from<K2>(x), m2, r);
+}
+
+template <int K>
+__device__ __forceinline__ v3 dpp3(v3 a, float m) {  // a of lane i+K, times the 0/1 mask m
+  return v3{dpp_from<K>(a.x) * m, dpp_from<K>(a.y) * m, dpp_from<K>(a.z) * m};
 }
 
 template <bool ISO>
@@ -233,16 +260,22 @@ __device__ __forceinline__ v3 iinv_z0(const Inert<ISO>& in, const WInert<ISO>& W
 // ISO   model-wide isotropic inverse inertia (spring_inertia_scale = 1 models: the humanoid)
 // SLIDES any slide dof in the model (planar roots of hopper / halfcheetah)
 // MAXCH max children of any link; MAXCOL max sphere colliders on any link
-template <int LPS, bool ISO, bool SLIDES, int MAXCH, int MAXCOL>
+// D0,D1,D2 (all non-zero, or all zero = off): DPP layout, lane(parent) = lane(s-th child) + Ds
+template <int LPS, bool ISO, bool SLIDES, int MAXCH, int MAXCOL, int D0 = 0, int D1 = 0, int D2 = 0>
 __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
+  constexpr bool DPP = D0 != 0;
+  static_assert(!DPP || (LPS == 16 && MAXCH == 3 && D1 != 0 && D2 != 0), "DPP layout: one 16-lane row, 3 slots");
   const mbd_model_t* __restrict__ M = P.model;
   const unsigned long long dbg_t0 = P.dbg_clock ? __builtin_amdgcn_s_memtime() : 0ull;
   const int lane = threadIdx.x & 63;
   const int base = lane & ~(LPS - 1);
-  const int l_raw = lane & (LPS - 1);
+  const int l_lane = lane & (LPS - 1);
   const int L = M->n_links;
-  const bool link_ok = l_raw < L;
-  const int l = link_ok ? l_raw : 0;
+  const int l_link = DPP ? (int)P.lane_tab[l_lane] : l_lane;  // the link this lane holds
+  const bool link_ok = l_link >= 0 && l_link < L;
+  const int l = link_ok ? l_link : 0;
+  auto lane_of = [&](int link) { return base + (DPP ? (int)P.lane_tab[16 + link] : link); };
+  const bool root_lane = link_ok && l == 0;  // the lane that owns link 0 (rewards, control cost)
   constexpr int SPW = 64 / LPS;
   const int b_raw = blockIdx.x * SPW + lane / LPS;
   const bool b_ok = b_raw < P.B;
@@ -254,7 +287,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
   const int nr = M->n_rot[l];
   const bool is_joint = link_ok && nr >= 0;
   const int ns = SLIDES ? M->n_slide[l] : 0;
-  const int plane = parent >= 0 ? base + parent : lane;  // lane holding the parent (self if world)
+  const int plane = parent >= 0 ? lane_of(parent) : lane;  // lane holding the parent (self if world)
   const bool world_parent = parent < 0;
   Inert<ISO> ic, ip;
   ic.inv_mass = M->inv_mass[l];
@@ -273,7 +306,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
   // compute is then an exact zero
   const float ang_damp = is_joint ? M->ang_damp[l] : 0.0f, vel_damp = is_joint ? M->vel_damp[l] : 0.0f;
   const int nr_eff = is_joint ? nr : -1;
-  const int zero_lane = M->n_rot[0] < 0 ? base : (L < LPS ? base + L : -1);  // a lane contributing zeros
+  const int zero_lane = M->n_rot[0] < 0 ? lane_of(0) : (L < LPS ? base + L : -1);  // a lane contributing zeros
   const bool need_child_mask = !(M->n_rot[0] < 0) && !(L < LPS);           // wave-uniform (scalar) flag
   float lim_lo[3], lim_hi[3], stiff[3], damp[3];
   v3 saxis[3];
@@ -307,7 +340,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       if (M->parent[c] == l && link_ok) {
 #pragma unroll
         for (int j = 0; j < MAXCH; ++j)
-          if (j == nc) child_lane[j] = base + c;
+          if (j == nc) child_lane[j] = lane_of(c);
         ++nc;
       }
   }
@@ -318,6 +351,18 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
   // branch per slot; a skipped slot would have added exact zeros
   const int max_children = P.max_children;
   auto child_slot = [&](int c) { return MAXCH <= 3 || c < max_children; };
+  // DPP layout: 0/1 masks — rm[s]: this link has an s-th child (it sits at lane - Ds); pm[s]: this link is the
+  // s-th child of its parent (which sits at lane + Ds)
+  float rm[3] = {0.0f, 0.0f, 0.0f}, pm[3] = {0.0f, 0.0f, 0.0f};
+  if constexpr (DPP) {
+    int myslot = -1;
+    if (link_ok && parent >= 0) {
+      myslot = 0;
+      for (int c = 0; c < l; ++c) myslot += M->parent[c] == parent ? 1 : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 3; ++k) { rm[k] = child_lane[k] >= 0 ? 1.0f : 0.0f; pm[k] = myslot == k ? 1.0f : 0.0f; }
+  }
   v3 col_pos[MAXCOL];
   float col_rad[MAXCOL];
   bool col_has[MAXCOL];
@@ -384,7 +429,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       tau_sl[k] = SLIDES ? fclip(act_sl[k] >= 0 ? u_sl[k] : 0.0f, alo_sl[k], ahi_sl[k]) * gear_sl[k] : 0.0f;
     }
     float ctrl_cost = 0.0f;
-    if ((rkind == MBD_REW_HALFCHEETAH || rkind == MBD_REW_ANT) && l_raw == 0) {
+    if ((rkind == MBD_REW_HALFCHEETAH || rkind == MBD_REW_ANT) && root_lane) {
       for (int a = 0; a < Nu; ++a) {
         float ua = u_row[(size_t)t * Nu + a];
         ctrl_cost = ctrl_cost + ua * ua;
@@ -452,15 +497,21 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       v3x2 acc = pack3(fc_v, fc_w);  // (linear, angular) acceleration, packed
       {
         v3 cv[MAXCH], cw[MAXCH];
+        if constexpr (DPP) {
+          cv[0] = dpp3<-D0>(fp_v, rm[0]); cw[0] = dpp3<-D0>(fp_w, rm[0]);
+          cv[1] = dpp3<-D1>(fp_v, rm[1]); cw[1] = dpp3<-D1>(fp_w, rm[1]);
+          cv[2] = dpp3<-D2>(fp_v, rm[2]); cw[2] = dpp3<-D2>(fp_w, rm[2]);
+        } else {
 #pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-          if (child_slot(c)) { cv[c] = shfl3(fp_v, child_src[c]); cw[c] = shfl3(fp_w, child_src[c]); }
+          for (int c = 0; c < MAXCH; ++c) {
+            if (child_slot(c)) { cv[c] = shfl3(fp_v, child_src[c]); cw[c] = shfl3(fp_w, child_src[c]); }
+          }
+          shfl_join();
         }
-        shfl_join();
 #pragma unroll
         for (int c = 0; c < MAXCH; ++c) {
           if (!child_slot(c)) continue;
-          if (need_child_mask) {  // no zero lane in this model: mask missing children (scalar branch)
+          if (!DPP && need_child_mask) {  // no zero lane in this model: mask missing children (scalar branch)
             cv[c] = sel3(child_lane[c] >= 0, cv[c], mk3(0, 0, 0));
             cw[c] = sel3(child_lane[c] >= 0, cw[c], mk3(0, 0, 0));
           }
@@ -476,9 +527,16 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       p = mk3(ffma(v.x, dt, p.x), ffma(v.y, dt, p.y), ffma(v.z, dt, p.z));
       r = qrotvec(r, scale(w, dt));
       // ---- (3) joints.position_update (Jacobi) ------------------------------------------------------
-      Pp = shfl3(p, plane);
-      Pr = shfl4(r, plane);
-      shfl_join();
+      if constexpr (DPP) {
+        Pp = v3{dpp_pick<D0, D1, D2>(p.x, pm[0], pm[1], pm[2]), dpp_pick<D0, D1, D2>(p.y, pm[0], pm[1], pm[2]),
+                dpp_pick<D0, D1, D2>(p.z, pm[0], pm[1], pm[2])};
+        Pr = q4{dpp_pick<D0, D1, D2>(r.w, pm[0], pm[1], pm[2]), dpp_pick<D0, D1, D2>(r.x, pm[0], pm[1], pm[2]),
+                dpp_pick<D0, D1, D2>(r.y, pm[0], pm[1], pm[2]), dpp_pick<D0, D1, D2>(r.z, pm[0], pm[1], pm[2])};
+      } else {
+        Pp = shfl3(p, plane);
+        Pr = shfl4(r, plane);
+        shfl_join();
+      }
       if constexpr (SLIDES) { Pp = sel3(world_parent, mk3(0, 0, 0), Pp); Pr = sel4(world_parent, q4{1, 0, 0, 0}, Pr); }
       v3 dc_p, dc_th, dp_p, dp_th;
       v3 cp[MAXCH], cth[MAXCH];
@@ -542,11 +600,13 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         // the translational corrections are final: the parent's share leaves now and its round trip hides
         // behind the angular limit corrections
         dc_p = hi3(lin2); dp_p = lo3(lin2);
+        if constexpr (!DPP) {
 #pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-          if (child_slot(c)) cp[c] = shfl3(dp_p, child_src[c]);
+          for (int c = 0; c < MAXCH; ++c) {
+            if (child_slot(c)) cp[c] = shfl3(dp_p, child_src[c]);
+          }
+          shfl_issue();
         }
-        shfl_issue();
         ang_apply(ca, q_ta.y, js_ang, dth2);
         // joint limits on the Euler angles: three corrections, quotients (0,1) packed, 2 alone
         auto viol_of = [&](int k, float a) {  // both differences first: selects, not branches
@@ -566,15 +626,21 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       }
       {
         v3x2 acc = pack3(dc_p, dc_th);  // (translation, rotation vector), packed
+        if constexpr (DPP) {
+          cp[0] = dpp3<-D0>(dp_p, rm[0]); cth[0] = dpp3<-D0>(dp_th, rm[0]);
+          cp[1] = dpp3<-D1>(dp_p, rm[1]); cth[1] = dpp3<-D1>(dp_th, rm[1]);
+          cp[2] = dpp3<-D2>(dp_p, rm[2]); cth[2] = dpp3<-D2>(dp_th, rm[2]);
+        } else {
 #pragma unroll
-        for (int c = 0; c < MAXCH; ++c) {
-          if (child_slot(c)) cth[c] = shfl3(dp_th, child_src[c]);
+          for (int c = 0; c < MAXCH; ++c) {
+            if (child_slot(c)) cth[c] = shfl3(dp_th, child_src[c]);
+          }
+          shfl_join();
         }
-        shfl_join();
 #pragma unroll
         for (int c = 0; c < MAXCH; ++c) {
           if (!child_slot(c)) continue;
-          if (need_child_mask) {
+          if (!DPP && need_child_mask) {
             cp[c] = sel3(child_lane[c] >= 0, cp[c], mk3(0, 0, 0));
             cth[c] = sel3(child_lane[c] >= 0, cth[c], mk3(0, 0, 0));
           }
@@ -684,9 +750,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       float sn, cs;
       sincos_(f.ang0, &sn, &cs);
       cart_vs = dot(vc, sx);                    // own slide-0 velocity: used on lane 0
-      cart_cos = shfl(cs, base + 1);            // cos of link 1's hinge angle, fetched by lane 0
+      cart_cos = shfl(cs, lane_of(1));          // cos of link 1's hinge angle, fetched by the root lane
     }
-    if (l_raw == 0) {
+    if (root_lane) {
       float rew;
       if (rkind == MBD_REW_HUMANOIDRUN) {
         rew = o1.x * 1.0f - fclip(fabs_(o1.z - 1.3f), -1.0f, 1.0f) * 1.0f - fabs_(o1.y) * 0.1f;
@@ -720,7 +786,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
     P.dbg_clock[blockIdx.x * 3 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |
                                       ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
   }
-  if (l_raw == 0 && b_ok && P.rews) P.rews[b] = rew_sum / (float)H;
+  if (root_lane && b_ok && P.rews) P.rews[b] = rew_sum / (float)H;
   if (P.state_final && link_ok && b_ok) {
     float* o = P.state_final + ((size_t)b * L + l) * MBD_LINK_STATE;
     o[0] = p.x; o[1] = p.y; o[2] = p.z; o[3] = r.w; o[4] = r.x; o[5] = r.y; o[6] = r.z;
