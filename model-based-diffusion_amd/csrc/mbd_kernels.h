@@ -78,10 +78,54 @@ __device__ __forceinline__ float dpp_pick(float x, float m0, float m1, float m2)
   return ffma(dpp_from<K2>(x), m2, r);
 }
 
+// v_fmac_f32 with a DPP source is not something the compiler forms (it keeps v_mov_b32_dpp + v_fmac_f32), so the
+// accumulating forms are written out.  acc += x(lane i+K) * m is bit-identical to an add when m is 1.0f and a
+// no-op when m is 0.0f.  The leading "s_nop 1" covers the hazard of a DPP read within two wait states of a VALU
+// write of the same register, which the compiler cannot see inside an asm block; the accumulators are only ever
+// consumed by ordinary VALU instructions.
+// (the modifier text must be a literal inside the asm string: one specialisation per shift in use)
 template <int K>
-__device__ __forceinline__ v3 dpp3(v3 a, float m) {  // a of lane i+K, times the 0/1 mask m
-  return v3{dpp_from<K>(a.x) * m, dpp_from<K>(a.y) * m, dpp_from<K>(a.z) * m};
-}
+__device__ __forceinline__ void dpp_acc6(v3& a, v3& b, v3 x, v3 y, float m);
+#define MBD_DPP_ACC6(K, MOD)                                                                                  \
+  template <>                                                                                                 \
+  __device__ __forceinline__ void dpp_acc6<K>(v3 & a, v3 & b, v3 x, v3 y, float m) {                          \
+    asm("s_nop 1\n\t"                                                                                         \
+        "v_fmac_f32_dpp %0, %6, %12 " MOD " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                      \
+        "v_fmac_f32_dpp %1, %7, %12 " MOD " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                      \
+        "v_fmac_f32_dpp %2, %8, %12 " MOD " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                      \
+        "v_fmac_f32_dpp %3, %9, %12 " MOD " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                      \
+        "v_fmac_f32_dpp %4, %10, %12 " MOD " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                     \
+        "v_fmac_f32_dpp %5, %11, %12 " MOD " row_mask:0xf bank_mask:0xf bound_ctrl:1"                          \
+        : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z)                                    \
+        : "v"(x.x), "v"(x.y), "v"(x.z), "v"(y.x), "v"(y.y), "v"(y.z), "v"(m));                                \
+  }
+MBD_DPP_ACC6(-1, "row_shr:1")
+MBD_DPP_ACC6(4, "row_shl:4")
+MBD_DPP_ACC6(6, "row_shl:6")
+#undef MBD_DPP_ACC6
+// the parent's pose for the s-th child (mask m_s = 1): seven values, r = x(i+K0) m0 + x(i+K1) m1 + x(i+K2) m2
+template <int K0, int K1, int K2>
+__device__ __forceinline__ void dpp_fetch7(v3 p, q4 r, float m0, float m1, float m2, v3& Pp, q4& Pr);
+#define MBD_DPP_F(R, X, M, MOD) "v_fmac_f32_dpp %" #R ", %" #X ", %" #M " " MOD " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define MBD_DPP_FETCH7(K0, K1, K2, MOD1, MOD2)                                                                \
+  template <>                                                                                                 \
+  __device__ __forceinline__ void dpp_fetch7<K0, K1, K2>(v3 p, q4 r, float m0, float m1, float m2, v3 & Pp,   \
+                                                         q4 & Pr) {                                           \
+    float o0 = dpp_from<K0>(p.x) * m0, o1 = dpp_from<K0>(p.y) * m0, o2 = dpp_from<K0>(p.z) * m0;              \
+    float o3 = dpp_from<K0>(r.w) * m0, o4 = dpp_from<K0>(r.x) * m0, o5 = dpp_from<K0>(r.y) * m0;              \
+    float o6 = dpp_from<K0>(r.z) * m0;                                                                        \
+    asm("s_nop 1\n\t" MBD_DPP_F(0, 7, 14, MOD1) MBD_DPP_F(1, 8, 14, MOD1) MBD_DPP_F(2, 9, 14, MOD1)           \
+            MBD_DPP_F(3, 10, 14, MOD1) MBD_DPP_F(4, 11, 14, MOD1) MBD_DPP_F(5, 12, 14, MOD1)                  \
+                MBD_DPP_F(6, 13, 14, MOD1) MBD_DPP_F(0, 7, 15, MOD2) MBD_DPP_F(1, 8, 15, MOD2)                \
+                    MBD_DPP_F(2, 9, 15, MOD2) MBD_DPP_F(3, 10, 15, MOD2) MBD_DPP_F(4, 11, 15, MOD2)           \
+                        MBD_DPP_F(5, 12, 15, MOD2) MBD_DPP_F(6, 13, 15, MOD2)                                 \
+        : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(o4), "+v"(o5), "+v"(o6)                                \
+        : "v"(p.x), "v"(p.y), "v"(p.z), "v"(r.w), "v"(r.x), "v"(r.y), "v"(r.z), "v"(m1), "v"(m2));            \
+    Pp = v3{o0, o1, o2};                                                                                      \
+    Pr = q4{o3, o4, o5, o6};                                                                                  \
+  }
+MBD_DPP_FETCH7(1, -4, -6, "row_shr:4", "row_shr:6")
+#undef MBD_DPP_FETCH7
 
 template <bool ISO>
 struct Inert {
@@ -497,10 +541,12 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       v3x2 acc = pack3(fc_v, fc_w);  // (linear, angular) acceleration, packed
       {
         v3 cv[MAXCH], cw[MAXCH];
-        if constexpr (DPP) {
-          cv[0] = dpp3<-D0>(fp_v, rm[0]); cw[0] = dpp3<-D0>(fp_w, rm[0]);
-          cv[1] = dpp3<-D1>(fp_v, rm[1]); cw[1] = dpp3<-D1>(fp_w, rm[1]);
-          cv[2] = dpp3<-D2>(fp_v, rm[2]); cw[2] = dpp3<-D2>(fp_w, rm[2]);
+        if constexpr (DPP) {  // ((own + child 0) + child 1) + child 2, as in the shuffle path
+          v3 sv = fc_v, sw = fc_w;
+          dpp_acc6<-D0>(sv, sw, fp_v, fp_w, rm[0]);
+          dpp_acc6<-D1>(sv, sw, fp_v, fp_w, rm[1]);
+          dpp_acc6<-D2>(sv, sw, fp_v, fp_w, rm[2]);
+          acc = pack3(sv, sw);
         } else {
 #pragma unroll
           for (int c = 0; c < MAXCH; ++c) {
@@ -510,8 +556,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         }
 #pragma unroll
         for (int c = 0; c < MAXCH; ++c) {
-          if (!child_slot(c)) continue;
-          if (!DPP && need_child_mask) {  // no zero lane in this model: mask missing children (scalar branch)
+          if (DPP || !child_slot(c)) continue;
+          if (need_child_mask) {  // no zero lane in this model: mask missing children (scalar branch)
             cv[c] = sel3(child_lane[c] >= 0, cv[c], mk3(0, 0, 0));
             cw[c] = sel3(child_lane[c] >= 0, cw[c], mk3(0, 0, 0));
           }
@@ -528,10 +574,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       r = qrotvec(r, scale(w, dt));
       // ---- (3) joints.position_update (Jacobi) ------------------------------------------------------
       if constexpr (DPP) {
-        Pp = v3{dpp_pick<D0, D1, D2>(p.x, pm[0], pm[1], pm[2]), dpp_pick<D0, D1, D2>(p.y, pm[0], pm[1], pm[2]),
-                dpp_pick<D0, D1, D2>(p.z, pm[0], pm[1], pm[2])};
-        Pr = q4{dpp_pick<D0, D1, D2>(r.w, pm[0], pm[1], pm[2]), dpp_pick<D0, D1, D2>(r.x, pm[0], pm[1], pm[2]),
-                dpp_pick<D0, D1, D2>(r.y, pm[0], pm[1], pm[2]), dpp_pick<D0, D1, D2>(r.z, pm[0], pm[1], pm[2])};
+        dpp_fetch7<D0, D1, D2>(p, r, pm[0], pm[1], pm[2], Pp, Pr);
       } else {
         Pp = shfl3(p, plane);
         Pr = shfl4(r, plane);
@@ -627,9 +670,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       {
         v3x2 acc = pack3(dc_p, dc_th);  // (translation, rotation vector), packed
         if constexpr (DPP) {
-          cp[0] = dpp3<-D0>(dp_p, rm[0]); cth[0] = dpp3<-D0>(dp_th, rm[0]);
-          cp[1] = dpp3<-D1>(dp_p, rm[1]); cth[1] = dpp3<-D1>(dp_th, rm[1]);
-          cp[2] = dpp3<-D2>(dp_p, rm[2]); cth[2] = dpp3<-D2>(dp_th, rm[2]);
+          v3 sp = dc_p, sth = dc_th;
+          dpp_acc6<-D0>(sp, sth, dp_p, dp_th, rm[0]);
+          dpp_acc6<-D1>(sp, sth, dp_p, dp_th, rm[1]);
+          dpp_acc6<-D2>(sp, sth, dp_p, dp_th, rm[2]);
+          acc = pack3(sp, sth);
         } else {
 #pragma unroll
           for (int c = 0; c < MAXCH; ++c) {
@@ -639,8 +684,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         }
 #pragma unroll
         for (int c = 0; c < MAXCH; ++c) {
-          if (!child_slot(c)) continue;
-          if (!DPP && need_child_mask) {
+          if (DPP || !child_slot(c)) continue;
+          if (need_child_mask) {
             cp[c] = sel3(child_lane[c] >= 0, cp[c], mk3(0, 0, 0));
             cth[c] = sel3(child_lane[c] >= 0, cth[c], mk3(0, 0, 0));
           }
