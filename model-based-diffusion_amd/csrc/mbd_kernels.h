@@ -613,7 +613,30 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           e = sel3(nr_eff == 0, mk3(sg * qe.x, sg * qe.y, sg * qe.z), e);
         }
         const AngPrep ca = ang_prepare<ISO>(e, ip, ic, W2);
-        const f2 q_ta = div2_(mk2(c2, ca.num), mk2(den, ca.den));  // translation and alignment quotients
+        // joint limits on the Euler angles: three more corrections. Their quotients (0,1) share a packed
+        // division, 2 goes alone.
+        auto viol_of = [&](int k, float a) {  // both differences first: selects, not branches
+          const float dlo = a - lim_lo[k], dhi = a - lim_hi[k];
+          float viol = a < lim_lo[k] ? dlo : (a > lim_hi[k] ? dhi : 0.0f);
+          return k < nr_eff ? viol : 0.0f;
+        };
+        AngPrep c0, c1, c2_;
+        auto limits_prepare = [&] {
+          c0 = ang_prepare<ISO>(scale(f.Xp, -viol_of(0, f.ang0)), ip, ic, W2);
+          c1 = ang_prepare<ISO>(scale(f.ax1, -viol_of(1, f.ang1)), ip, ic, W2);
+          c2_ = ang_prepare<ISO>(scale(f.Zc, -viol_of(2, f.ang2)), ip, ic, W2);
+        };
+        f2 q_ta, q01;  // (translation, alignment) and (limit 0, limit 1) quotients
+        float q2;
+        if constexpr (DPP) {
+          // no exchange latency to hide here: all divisions run as interleaved independent chains (a dependent
+          // packed FMA costs a wait state, which the compiler fills with s_nop when nothing else is at hand)
+          limits_prepare();
+          div2x2_(mk2(c2, ca.num), mk2(den, ca.den), mk2(c0.num, c1.num), mk2(c0.den, c1.den), q_ta, q01);
+          q2 = div_(c2_.num, c2_.den);
+        } else {
+          q_ta = div2_(mk2(c2, ca.num), mk2(den, ca.den));
+        }
         float g = q_ta.x * js_pos;
         const v3x2 P2 = bcast3(scale(d, g));
         const v3x2 lin = scale2(P2, mk2(-ip.inv_mass, ic.inv_mass));  // (dp_p, dc_p)
@@ -651,17 +674,11 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           shfl_issue();
         }
         ang_apply(ca, q_ta.y, js_ang, dth2);
-        // joint limits on the Euler angles: three corrections, quotients (0,1) packed, 2 alone
-        auto viol_of = [&](int k, float a) {  // both differences first: selects, not branches
-          const float dlo = a - lim_lo[k], dhi = a - lim_hi[k];
-          float viol = a < lim_lo[k] ? dlo : (a > lim_hi[k] ? dhi : 0.0f);
-          return k < nr_eff ? viol : 0.0f;
-        };
-        const AngPrep c0 = ang_prepare<ISO>(scale(f.Xp, -viol_of(0, f.ang0)), ip, ic, W2);
-        const AngPrep c1 = ang_prepare<ISO>(scale(f.ax1, -viol_of(1, f.ang1)), ip, ic, W2);
-        const AngPrep c2_ = ang_prepare<ISO>(scale(f.Zc, -viol_of(2, f.ang2)), ip, ic, W2);
-        const f2 q01 = div2_(mk2(c0.num, c1.num), mk2(c0.den, c1.den));
-        const float q2 = div_(c2_.num, c2_.den);
+        if constexpr (!DPP) {  // (the shuffled kernels keep this work behind the translational exchange)
+          limits_prepare();
+          q01 = div2_(mk2(c0.num, c1.num), mk2(c0.den, c1.den));
+          q2 = div_(c2_.num, c2_.den);
+        }
         ang_apply(c0, q01.x, js_ang, dth2);
         ang_apply(c1, q01.y, js_ang, dth2);
         ang_apply(c2_, q2, js_ang, dth2);

@@ -198,6 +198,22 @@ __device__ __forceinline__ f2 div2_(f2 n, f2 d) {
   return fma2(e, r, q);
 }
 
+// two packed divisions as interleaved chains (same arithmetic as two div2_ calls)
+__device__ __forceinline__ void div2x2_(f2 na, f2 da, f2 nb, f2 db, f2& qa_out, f2& qb_out) {
+  na = mk2(fabs_(na.x) < 1e-28f ? 0.0f : na.x, fabs_(na.y) < 1e-28f ? 0.0f : na.y);
+  nb = mk2(fabs_(nb.x) < 1e-28f ? 0.0f : nb.x, fabs_(nb.y) < 1e-28f ? 0.0f : nb.y);
+  f2 ra = mk2(__builtin_amdgcn_rcpf(da.x), __builtin_amdgcn_rcpf(da.y));
+  f2 rb = mk2(__builtin_amdgcn_rcpf(db.x), __builtin_amdgcn_rcpf(db.y));
+  const f2 one = mk2(1.0f, 1.0f);
+  f2 ea = fma2(-da, ra, one), eb = fma2(-db, rb, one);
+  ra = fma2(ea, ra, ra); rb = fma2(eb, rb, rb);
+  f2 qa = na * ra, qb = nb * rb;
+  ea = fma2(-da, qa, na); eb = fma2(-db, qb, nb);
+  qa = fma2(ea, ra, qa); qb = fma2(eb, rb, qb);
+  ea = fma2(-da, qa, na); eb = fma2(-db, qb, nb);
+  qa_out = fma2(ea, ra, qa); qb_out = fma2(eb, rb, qb);
+}
+
 // angle of the near-unit vector (c, s) in (-pi, pi], division-free: asin of min(|s|,|c|) + octant fix-ups
 MBD_HD float angle_unit(float s, float c) {
   float as = fabs_(s), ac = fabs_(c);

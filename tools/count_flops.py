@@ -14,7 +14,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_ZN3mbd14rollout_kernelILi16ELb1ELb0ELi3ELi1EEEvNS_13RolloutParamsE"
+KERNEL = "_ZN3mbd14rollout_kernelILi16ELb1ELb0ELi3ELi1ELi1ELin4ELin6EEEvNS_13RolloutParamsE"
 
 
 def main():
@@ -22,7 +22,7 @@ def main():
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "k.hip")
         with open(src, "w") as f:
-            f.write(f'#include "{csrc}/mbd_kernels.h"\ntemplate __global__ void mbd::rollout_kernel<16,true,false,3,1>(mbd::RolloutParams);\n')
+            f.write(f'#include "{csrc}/mbd_kernels.h"\ntemplate __global__ void mbd::rollout_kernel<16,true,false,3,1,1,-4,-6>(mbd::RolloutParams);\n')
         out = os.path.join(td, "k.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                         "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-S", "--cuda-device-only", src,
@@ -41,11 +41,12 @@ def main():
         m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
         if m and m.group(1) in lab and lab[m.group(1)] < k:
             ins = [x.strip().split()[0] for x in body[lab[m.group(1)]:k + 1]
-                   if x.startswith("\t") and not x.strip().startswith((".", ";"))]
-            loops.append((sum(1 for i in ins if i.startswith("ds_")), ins))
-    # the substep loop = the smallest loop holding the 56 ds_bpermute of one substep (13 + 18 + 7 + 18); the
-    # control-step loop around it holds them too (plus the cartpole reward's), but is longer
-    best = min((ins for n, ins in loops if n >= 56), key=len)
+                   if x.startswith("\t") and x.strip() and not x.strip().startswith((".", ";"))]
+            loops.append((sum(1 for i in ins if i.startswith("ds_")), sum(1 for i in ins if "dpp" in i), ins))
+    # the substep loop = the smallest loop holding one substep's exchanges: 13 ds_bpermute (the parent's state,
+    # prefetched) and the DPP row shifts of the parent<->child traffic; the control-step loop around it holds
+    # them too (plus the cartpole reward's), but is longer
+    best = min((ins for n, d, ins in loops if n >= 13 and d >= 30), key=len)
     c = collections.Counter(best)
     flops = 0
     for k, v in c.items():
@@ -53,7 +54,7 @@ def main():
             flops += 4 * v
         elif k.startswith(("v_pk_mul_f32", "v_pk_add_f32")):
             flops += 2 * v
-        elif k.startswith(("v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32")):
+        elif k.startswith(("v_fma_f32", "v_fmac_f32", "v_fmaak_f32", "v_fmamk_f32")):  # (incl. v_fmac_f32_dpp)
             flops += 2 * v
         elif k.startswith(("v_mul_f32", "v_add_f32", "v_sub_f32", "v_rcp_f32", "v_sqrt_f32", "v_div_")):
             flops += v
