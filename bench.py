@@ -237,7 +237,7 @@ def main():
                        "collective": "all_gather(rews) per step" if distributed else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "rollout_kernel<16,iso,noslide,3,1>", "kernel_avg_ms": kern_ms,
+                         "kernel": "rollout_kernel<16,iso,noslide,3,1,dpp(1,-4,-6)>", "kernel_avg_ms": kern_ms,
                          "kernel_launches": kern_n, "algorithmic_bytes_per_launch": balg,
                          "note": "state stays in VGPRs for all H*n_frames substeps: the kernel is bound by "
                                  "dependent FP32 VALU issue, not HBM (DESIGN.md §Roofline)"},
