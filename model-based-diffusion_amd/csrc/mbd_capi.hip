@@ -73,7 +73,7 @@ struct mbd_env {
   bool slides = false;
   bool slide_limits = false;  // any slide dof with a finite range
   // DPP layout (kernels.h "lane exchange without the LDS"): lane <-> link tables when the tree fits the shifts
-  bool dpp_ok = false;
+  int dpp_family = -1;  // index into kDppFamilies, -1: shuffles
   signed char lane_tab[32];
   signed char* d_lane_tab = nullptr;
   // scratch for the single-env step path
@@ -101,14 +101,14 @@ struct mbd_plan {
 
 namespace {
 
-// The DPP instantiations are built for the humanoid family's tree: lane(parent) = lane(s-th child) + kDppDs.
-// A model qualifies if some root lane puts every link on a distinct lane of the 16-lane row.
-constexpr int kDppD0 = 1, kDppD1 = -4, kDppD2 = -6;
-bool find_dpp_layout(const mbd_model_t& m, signed char tab[32]) {
-  const int D[3] = {kDppD0, kDppD1, kDppD2};
+// DPP layouts the kernels are instantiated for: lane(parent) = lane(s-th child) + D[s] (0: the family has no such
+// slot).  A model qualifies for a family if some root lane puts every link on a distinct lane of its LPS-lane group.
+constexpr int kDppD0 = 1, kDppD1 = -4, kDppD2 = -6;  // humanoid family: up to three children per link
+constexpr int kDppFamilies[3][3] = {{kDppD0, kDppD1, kDppD2}, {1, -3, 0} /* two-legged planar */, {1, 0, 0} /* chain */};
+bool find_dpp_layout(const mbd_model_t& m, int lps, const int D[3], signed char tab[32]) {
   const int L = m.n_links;
-  if (L > 16) return false;
-  for (int root = 0; root < 16; ++root) {
+  if (L > lps) return false;
+  for (int root = 0; root < lps; ++root) {
     int lane[MBD_MAX_LINKS];
     bool used[16] = {false}, ok = true;
     for (int l = 0; l < L && ok; ++l) {
@@ -119,10 +119,10 @@ bool find_dpp_layout(const mbd_model_t& m, signed char tab[32]) {
         if (m.parent[l] >= l) { ok = false; break; }
         int slot = 0;
         for (int c = 0; c < l; ++c) slot += m.parent[c] == m.parent[l] ? 1 : 0;
-        if (slot > 2) { ok = false; break; }
+        if (slot > 2 || D[slot] == 0) { ok = false; break; }
         lane[l] = lane[m.parent[l]] - D[slot];
       }
-      if (lane[l] < 0 || lane[l] > 15 || used[lane[l]]) { ok = false; break; }
+      if (lane[l] < 0 || lane[l] >= lps || used[lane[l]]) { ok = false; break; }
       used[lane[l]] = true;
     }
     if (!ok) continue;
@@ -150,9 +150,10 @@ int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B
 #define MBD_LAUNCH(LPS, ISO, SL, CH, COL) \
   hipLaunchKernelGGL((rollout_kernel<LPS, ISO, SL, CH, COL>), grid, block, 0, stream, P)
   const bool humanoid_shape = env->lps == 16 && iso && !env->slides && env->max_children <= 3;
-  if (humanoid_shape && env->max_col <= 1 && env->dpp_ok) {
+  const bool dpp_h = env->dpp_family == 0;
+  if (humanoid_shape && env->max_col <= 1 && dpp_h) {
     hipLaunchKernelGGL((rollout_kernel<16, true, false, 3, 1, kDppD0, kDppD1, kDppD2>), grid, block, 0, stream, P);
-  } else if (humanoid_shape && env->max_col <= 5 && env->dpp_ok) {
+  } else if (humanoid_shape && env->max_col <= 5 && dpp_h) {
     hipLaunchKernelGGL((rollout_kernel<16, true, false, 3, 5, kDppD0, kDppD1, kDppD2>), grid, block, 0, stream, P);
   } else if (humanoid_shape && env->max_col <= 1) {
     MBD_LAUNCH(16, true, false, 3, 1);  // humanoid-like trees that do not fit the DPP shifts
@@ -162,8 +163,17 @@ int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B
     MBD_LAUNCH(16, true, false, 4, 2);  // ant: free root with four legs, no slide / weld joints
   } else if (env->lps == 16) {
     if (iso) MBD_LAUNCH(16, true, true, 4, 2); else MBD_LAUNCH(16, false, true, 4, 2);
+  } else if (env->lps == 8 && env->dpp_family == 1) {  // walker2d, halfcheetah
+    if (iso) hipLaunchKernelGGL((rollout_kernel<8, true, true, 4, 2, 1, -3, 0>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((rollout_kernel<8, false, true, 4, 2, 1, -3, 0>), grid, block, 0, stream, P);
+  } else if (env->lps == 8 && env->dpp_family == 2) {
+    if (iso) hipLaunchKernelGGL((rollout_kernel<8, true, true, 4, 2, 1, 0, 0>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((rollout_kernel<8, false, true, 4, 2, 1, 0, 0>), grid, block, 0, stream, P);
   } else if (env->lps == 8) {
     if (iso) MBD_LAUNCH(8, true, true, 4, 2); else MBD_LAUNCH(8, false, true, 4, 2);
+  } else if (env->dpp_family == 2) {  // hopper, cartpole
+    if (iso) hipLaunchKernelGGL((rollout_kernel<4, true, true, 4, 2, 1, 0, 0>), grid, block, 0, stream, P);
+    else hipLaunchKernelGGL((rollout_kernel<4, false, true, 4, 2, 1, 0, 0>), grid, block, 0, stream, P);
   } else {
     if (iso) MBD_LAUNCH(4, true, true, 4, 2); else MBD_LAUNCH(4, false, true, 4, 2);
   }
@@ -360,8 +370,10 @@ extern "C" int mbd_env_create_model(const char* env_name, int device, const mbd_
       return fail(MBD_ERR_UNSUPPORTED, "a link has %d sphere colliders: more than this kernel family is built for", mc);
     }
   }
-  e->dpp_ok = e->lps == 16 && find_dpp_layout(m, e->lane_tab);
-  if (!e->dpp_ok)
+  // smallest family first: a chain also fits the wider layouts, but their kernels spend VALU slots on empty slots
+  for (int fam = 2; fam >= 0 && e->dpp_family < 0; --fam)
+    if ((fam == 0) == (e->lps == 16) && find_dpp_layout(m, e->lps, kDppFamilies[fam], e->lane_tab)) e->dpp_family = fam;
+  if (e->dpp_family < 0)
     for (int i = 0; i < 32; ++i) e->lane_tab[i] = (signed char)(i & 15);  // identity (unused by the other kernels)
   HIP_TRY(hipMalloc(&e->d_lane_tab, sizeof(e->lane_tab)));
   HIP_TRY(hipMemcpy(e->d_lane_tab, e->lane_tab, sizeof(e->lane_tab), hipMemcpyHostToDevice));

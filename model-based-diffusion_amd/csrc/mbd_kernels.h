@@ -102,6 +102,7 @@ __device__ __forceinline__ void dpp_acc6(v3& a, v3& b, v3 x, v3 y, float m);
 MBD_DPP_ACC6(-1, "row_shr:1")
 MBD_DPP_ACC6(4, "row_shl:4")
 MBD_DPP_ACC6(6, "row_shl:6")
+MBD_DPP_ACC6(3, "row_shl:3")
 #undef MBD_DPP_ACC6
 // the parent's pose for the s-th child (mask m_s = 1): seven values, r = x(i+K0) m0 + x(i+K1) m1 + x(i+K2) m2
 template <int K0, int K1, int K2>
@@ -126,6 +127,25 @@ __device__ __forceinline__ void dpp_fetch7(v3 p, q4 r, float m0, float m1, float
   }
 MBD_DPP_FETCH7(1, -4, -6, "row_shr:4", "row_shr:6")
 #undef MBD_DPP_FETCH7
+// trees with at most two children per link (walker2d, halfcheetah: D = (+1, -3)) and chains (hopper, cartpole)
+template <>
+__device__ __forceinline__ void dpp_fetch7<1, -3, 0>(v3 p, q4 r, float m0, float m1, float, v3& Pp, q4& Pr) {
+  float o0 = dpp_from<1>(p.x) * m0, o1 = dpp_from<1>(p.y) * m0, o2 = dpp_from<1>(p.z) * m0;
+  float o3 = dpp_from<1>(r.w) * m0, o4 = dpp_from<1>(r.x) * m0, o5 = dpp_from<1>(r.y) * m0;
+  float o6 = dpp_from<1>(r.z) * m0;
+  asm("s_nop 1\n\t" MBD_DPP_F(0, 7, 14, "row_shr:3") MBD_DPP_F(1, 8, 14, "row_shr:3") MBD_DPP_F(2, 9, 14, "row_shr:3")
+          MBD_DPP_F(3, 10, 14, "row_shr:3") MBD_DPP_F(4, 11, 14, "row_shr:3") MBD_DPP_F(5, 12, 14, "row_shr:3")
+              MBD_DPP_F(6, 13, 14, "row_shr:3")
+      : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(o4), "+v"(o5), "+v"(o6)
+      : "v"(p.x), "v"(p.y), "v"(p.z), "v"(r.w), "v"(r.x), "v"(r.y), "v"(r.z), "v"(m1));
+  Pp = v3{o0, o1, o2};
+  Pr = q4{o3, o4, o5, o6};
+}
+template <>
+__device__ __forceinline__ void dpp_fetch7<1, 0, 0>(v3 p, q4 r, float m0, float, float, v3& Pp, q4& Pr) {
+  Pp = v3{dpp_from<1>(p.x) * m0, dpp_from<1>(p.y) * m0, dpp_from<1>(p.z) * m0};
+  Pr = q4{dpp_from<1>(r.w) * m0, dpp_from<1>(r.x) * m0, dpp_from<1>(r.y) * m0, dpp_from<1>(r.z) * m0};
+}
 
 template <bool ISO>
 struct Inert {
@@ -304,11 +324,13 @@ __device__ __forceinline__ v3 iinv_z0(const Inert<ISO>& in, const WInert<ISO>& W
 // ISO   model-wide isotropic inverse inertia (spring_inertia_scale = 1 models: the humanoid)
 // SLIDES any slide dof in the model (planar roots of hopper / halfcheetah)
 // MAXCH max children of any link; MAXCOL max sphere colliders on any link
-// D0,D1,D2 (all non-zero, or all zero = off): DPP layout, lane(parent) = lane(s-th child) + Ds
+// D0,D1,D2: DPP layout, lane(parent) = lane(s-th child) + Ds (D0 = 0: off; a trailing 0: the model has no such
+// slot).  Groups of LPS lanes never straddle a 16-lane DPP row, and the 0/1 masks discard whatever a shift
+// pulls in from a neighbouring candidate of the same row.
 template <int LPS, bool ISO, bool SLIDES, int MAXCH, int MAXCOL, int D0 = 0, int D1 = 0, int D2 = 0>
 __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
   constexpr bool DPP = D0 != 0;
-  static_assert(!DPP || (LPS == 16 && MAXCH == 3 && D1 != 0 && D2 != 0), "DPP layout: one 16-lane row, 3 slots");
+  static_assert(!DPP || (D1 != 0 || D2 == 0), "DPP layout: slots are filled in order");
   const mbd_model_t* __restrict__ M = P.model;
   const unsigned long long dbg_t0 = P.dbg_clock ? __builtin_amdgcn_s_memtime() : 0ull;
   const int lane = threadIdx.x & 63;
@@ -544,8 +566,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         if constexpr (DPP) {  // ((own + child 0) + child 1) + child 2, as in the shuffle path
           v3 sv = fc_v, sw = fc_w;
           dpp_acc6<-D0>(sv, sw, fp_v, fp_w, rm[0]);
-          dpp_acc6<-D1>(sv, sw, fp_v, fp_w, rm[1]);
-          dpp_acc6<-D2>(sv, sw, fp_v, fp_w, rm[2]);
+          if constexpr (D1 != 0) dpp_acc6<-D1>(sv, sw, fp_v, fp_w, rm[1]);
+          if constexpr (D2 != 0) dpp_acc6<-D2>(sv, sw, fp_v, fp_w, rm[2]);
           acc = pack3(sv, sw);
         } else {
 #pragma unroll
@@ -689,8 +711,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         if constexpr (DPP) {
           v3 sp = dc_p, sth = dc_th;
           dpp_acc6<-D0>(sp, sth, dp_p, dp_th, rm[0]);
-          dpp_acc6<-D1>(sp, sth, dp_p, dp_th, rm[1]);
-          dpp_acc6<-D2>(sp, sth, dp_p, dp_th, rm[2]);
+          if constexpr (D1 != 0) dpp_acc6<-D1>(sp, sth, dp_p, dp_th, rm[1]);
+          if constexpr (D2 != 0) dpp_acc6<-D2>(sp, sth, dp_p, dp_th, rm[2]);
           acc = pack3(sp, sth);
         } else {
 #pragma unroll
