@@ -104,8 +104,11 @@ namespace {
 // DPP layouts the kernels are instantiated for: lane(parent) = lane(s-th child) + D[s] (0: the family has no such
 // slot).  A model qualifies for a family if some root lane puts every link on a distinct lane of its LPS-lane group.
 constexpr int kDppD0 = 1, kDppD1 = -4, kDppD2 = -6;  // humanoid family: up to three children per link
-constexpr int kDppFamilies[3][3] = {{kDppD0, kDppD1, kDppD2}, {1, -3, 0} /* two-legged planar */, {1, 0, 0} /* chain */};
-bool find_dpp_layout(const mbd_model_t& m, int lps, const int D[3], signed char tab[32]) {
+constexpr int kDppFamilies[4][4] = {{kDppD0, kDppD1, kDppD2, 0},
+                                    {1, -3, 0, 0} /* two-legged planar */,
+                                    {1, 0, 0, 0} /* chain */,
+                                    {1, -2, -4, -6} /* ant: four two-link legs */};
+bool find_dpp_layout(const mbd_model_t& m, int lps, const int D[4], signed char tab[32]) {
   const int L = m.n_links;
   if (L > lps) return false;
   for (int root = 0; root < lps; ++root) {
@@ -119,7 +122,7 @@ bool find_dpp_layout(const mbd_model_t& m, int lps, const int D[3], signed char 
         if (m.parent[l] >= l) { ok = false; break; }
         int slot = 0;
         for (int c = 0; c < l; ++c) slot += m.parent[c] == m.parent[l] ? 1 : 0;
-        if (slot > 2 || D[slot] == 0) { ok = false; break; }
+        if (slot > 3 || D[slot] == 0) { ok = false; break; }
         lane[l] = lane[m.parent[l]] - D[slot];
       }
       if (lane[l] < 0 || lane[l] >= lps || used[lane[l]]) { ok = false; break; }
@@ -159,8 +162,10 @@ int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B
     MBD_LAUNCH(16, true, false, 3, 1);  // humanoid-like trees that do not fit the DPP shifts
   } else if (humanoid_shape && env->max_col <= 5) {
     MBD_LAUNCH(16, true, false, 3, 5);  // humanoidstandup: up to 5 sphere colliders on one link
+  } else if (env->lps == 16 && iso && !env->slides && env->max_col <= 2 && env->dpp_family == 3) {
+    hipLaunchKernelGGL((rollout_kernel<16, true, false, 4, 2, 1, -2, -4, -6>), grid, block, 0, stream, P);  // ant
   } else if (env->lps == 16 && iso && !env->slides && env->max_col <= 2) {
-    MBD_LAUNCH(16, true, false, 4, 2);  // ant: free root with four legs, no slide / weld joints
+    MBD_LAUNCH(16, true, false, 4, 2);  // ant-like: free root with four legs, no slide / weld joints
   } else if (env->lps == 16) {
     if (iso) MBD_LAUNCH(16, true, true, 4, 2); else MBD_LAUNCH(16, false, true, 4, 2);
   } else if (env->lps == 8 && env->dpp_family == 1) {  // walker2d, halfcheetah
@@ -371,8 +376,13 @@ extern "C" int mbd_env_create_model(const char* env_name, int device, const mbd_
     }
   }
   // smallest family first: a chain also fits the wider layouts, but their kernels spend VALU slots on empty slots
-  for (int fam = 2; fam >= 0 && e->dpp_family < 0; --fam)
-    if ((fam == 0) == (e->lps == 16) && find_dpp_layout(m, e->lps, kDppFamilies[fam], e->lane_tab)) e->dpp_family = fam;
+  {
+    const int order16[2] = {0, 3}, order_small[2] = {2, 1};
+    for (int t = 0; t < 2 && e->dpp_family < 0; ++t) {
+      const int fam = e->lps == 16 ? order16[t] : order_small[t];
+      if (find_dpp_layout(m, e->lps, kDppFamilies[fam], e->lane_tab)) e->dpp_family = fam;
+    }
+  }
   if (e->dpp_family < 0)
     for (int i = 0; i < 32; ++i) e->lane_tab[i] = (signed char)(i & 15);  // identity (unused by the other kernels)
   HIP_TRY(hipMalloc(&e->d_lane_tab, sizeof(e->lane_tab)));

@@ -103,6 +103,7 @@ MBD_DPP_ACC6(-1, "row_shr:1")
 MBD_DPP_ACC6(4, "row_shl:4")
 MBD_DPP_ACC6(6, "row_shl:6")
 MBD_DPP_ACC6(3, "row_shl:3")
+MBD_DPP_ACC6(2, "row_shl:2")
 #undef MBD_DPP_ACC6
 // the parent's pose for the s-th child (mask m_s = 1): seven values, r = x(i+K0) m0 + x(i+K1) m1 + x(i+K2) m2
 template <int K0, int K1, int K2>
@@ -126,7 +127,19 @@ __device__ __forceinline__ void dpp_fetch7(v3 p, q4 r, float m0, float m1, float
     Pr = q4{o3, o4, o5, o6};                                                                                  \
   }
 MBD_DPP_FETCH7(1, -4, -6, "row_shr:4", "row_shr:6")
+MBD_DPP_FETCH7(1, -2, -4, "row_shr:2", "row_shr:4")
 #undef MBD_DPP_FETCH7
+// a fourth slot (ant: four legs on the torso): one more masked term on top of dpp_fetch7
+template <int K>
+__device__ __forceinline__ void dpp_fmac7(v3 p, q4 r, float m, v3& Pp, q4& Pr);
+template <>
+__device__ __forceinline__ void dpp_fmac7<-6>(v3 p, q4 r, float m, v3& Pp, q4& Pr) {
+  asm("s_nop 1\n\t" MBD_DPP_F(0, 7, 14, "row_shr:6") MBD_DPP_F(1, 8, 14, "row_shr:6") MBD_DPP_F(2, 9, 14, "row_shr:6")
+          MBD_DPP_F(3, 10, 14, "row_shr:6") MBD_DPP_F(4, 11, 14, "row_shr:6") MBD_DPP_F(5, 12, 14, "row_shr:6")
+              MBD_DPP_F(6, 13, 14, "row_shr:6")
+      : "+v"(Pp.x), "+v"(Pp.y), "+v"(Pp.z), "+v"(Pr.w), "+v"(Pr.x), "+v"(Pr.y), "+v"(Pr.z)
+      : "v"(p.x), "v"(p.y), "v"(p.z), "v"(r.w), "v"(r.x), "v"(r.y), "v"(r.z), "v"(m));
+}
 // trees with at most two children per link (walker2d, halfcheetah: D = (+1, -3)) and chains (hopper, cartpole)
 template <>
 __device__ __forceinline__ void dpp_fetch7<1, -3, 0>(v3 p, q4 r, float m0, float m1, float, v3& Pp, q4& Pr) {
@@ -324,13 +337,14 @@ __device__ __forceinline__ v3 iinv_z0(const Inert<ISO>& in, const WInert<ISO>& W
 // ISO   model-wide isotropic inverse inertia (spring_inertia_scale = 1 models: the humanoid)
 // SLIDES any slide dof in the model (planar roots of hopper / halfcheetah)
 // MAXCH max children of any link; MAXCOL max sphere colliders on any link
-// D0,D1,D2: DPP layout, lane(parent) = lane(s-th child) + Ds (D0 = 0: off; a trailing 0: the model has no such
+// D0..D3: DPP layout, lane(parent) = lane(s-th child) + Ds (D0 = 0: off; a trailing 0: the model has no such
 // slot).  Groups of LPS lanes never straddle a 16-lane DPP row, and the 0/1 masks discard whatever a shift
 // pulls in from a neighbouring candidate of the same row.
-template <int LPS, bool ISO, bool SLIDES, int MAXCH, int MAXCOL, int D0 = 0, int D1 = 0, int D2 = 0>
+template <int LPS, bool ISO, bool SLIDES, int MAXCH, int MAXCOL, int D0 = 0, int D1 = 0, int D2 = 0, int D3 = 0>
 __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
   constexpr bool DPP = D0 != 0;
-  static_assert(!DPP || (D1 != 0 || D2 == 0), "DPP layout: slots are filled in order");
+  static_assert(!DPP || ((D1 != 0 || D2 == 0) && (D2 != 0 || D3 == 0) && (D3 == 0 || MAXCH >= 4)),
+                "DPP layout: slots are filled in order");
   const mbd_model_t* __restrict__ M = P.model;
   const unsigned long long dbg_t0 = P.dbg_clock ? __builtin_amdgcn_s_memtime() : 0ull;
   const int lane = threadIdx.x & 63;
@@ -419,7 +433,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
   auto child_slot = [&](int c) { return MAXCH <= 3 || c < max_children; };
   // DPP layout: 0/1 masks — rm[s]: this link has an s-th child (it sits at lane - Ds); pm[s]: this link is the
   // s-th child of its parent (which sits at lane + Ds)
-  float rm[3] = {0.0f, 0.0f, 0.0f}, pm[3] = {0.0f, 0.0f, 0.0f};
+  float rm[4] = {0.0f, 0.0f, 0.0f, 0.0f}, pm[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   if constexpr (DPP) {
     int myslot = -1;
     if (link_ok && parent >= 0) {
@@ -427,7 +441,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       for (int c = 0; c < l; ++c) myslot += M->parent[c] == parent ? 1 : 0;
     }
 #pragma unroll
-    for (int k = 0; k < 3; ++k) { rm[k] = child_lane[k] >= 0 ? 1.0f : 0.0f; pm[k] = myslot == k ? 1.0f : 0.0f; }
+    for (int k = 0; k < (MAXCH < 4 ? MAXCH : 4); ++k) {
+      rm[k] = child_lane[k] >= 0 ? 1.0f : 0.0f;
+      pm[k] = myslot == k ? 1.0f : 0.0f;
+    }
   }
   v3 col_pos[MAXCOL];
   float col_rad[MAXCOL];
@@ -568,6 +585,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           dpp_acc6<-D0>(sv, sw, fp_v, fp_w, rm[0]);
           if constexpr (D1 != 0) dpp_acc6<-D1>(sv, sw, fp_v, fp_w, rm[1]);
           if constexpr (D2 != 0) dpp_acc6<-D2>(sv, sw, fp_v, fp_w, rm[2]);
+          if constexpr (D3 != 0) dpp_acc6<-D3>(sv, sw, fp_v, fp_w, rm[3]);
           acc = pack3(sv, sw);
         } else {
 #pragma unroll
@@ -597,6 +615,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       // ---- (3) joints.position_update (Jacobi) ------------------------------------------------------
       if constexpr (DPP) {
         dpp_fetch7<D0, D1, D2>(p, r, pm[0], pm[1], pm[2], Pp, Pr);
+        if constexpr (D3 != 0) dpp_fmac7<D3>(p, r, pm[3], Pp, Pr);
       } else {
         Pp = shfl3(p, plane);
         Pr = shfl4(r, plane);
@@ -713,6 +732,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           dpp_acc6<-D0>(sp, sth, dp_p, dp_th, rm[0]);
           if constexpr (D1 != 0) dpp_acc6<-D1>(sp, sth, dp_p, dp_th, rm[1]);
           if constexpr (D2 != 0) dpp_acc6<-D2>(sp, sth, dp_p, dp_th, rm[2]);
+          if constexpr (D3 != 0) dpp_acc6<-D3>(sp, sth, dp_p, dp_th, rm[3]);
           acc = pack3(sp, sth);
         } else {
 #pragma unroll
