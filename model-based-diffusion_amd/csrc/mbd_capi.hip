@@ -6,6 +6,7 @@
 #include <chrono>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -377,8 +378,11 @@ extern "C" int mbd_env_create_model(const char* env_name, int device, const mbd_
   }
   // smallest family first: a chain also fits the wider layouts, but their kernels spend VALU slots on empty slots
   {
+    // MBD_NO_DPP=1 keeps the shuffle (ds_bpermute) exchange: the fallback for trees that fit no DPP family,
+    // exercised by the test-suite this way
+    const char* no_dpp = std::getenv("MBD_NO_DPP");
     const int order16[2] = {0, 3}, order_small[2] = {2, 1};
-    for (int t = 0; t < 2 && e->dpp_family < 0; ++t) {
+    for (int t = 0; t < 2 && e->dpp_family < 0 && !(no_dpp && no_dpp[0] == '1'); ++t) {
       const int fam = e->lps == 16 ? order16[t] : order_small[t];
       if (find_dpp_layout(m, e->lps, kDppFamilies[fam], e->lane_tab)) e->dpp_family = fam;
     }

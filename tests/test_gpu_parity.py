@@ -90,6 +90,20 @@ def test_sample_kernel_reproduces_published_jax_normals(gpu, orc, impl, seed, wa
                                             ("ant", 44, 50, 0.5), ("car2d", 128, 30, 0.5),
                                             ("car2d", 3, 50, 1.0)])
 def test_rollout_bitexact(gpu, orc, name, B, H, sigma):
+    _rollout_bitexact(gpu, orc, name, B, H, sigma)
+
+
+@pytest.mark.parametrize("name,B,H,sigma", [("humanoidrun", 40, 50, 0.6), ("humanoidstandup", 20, 30, 0.5),
+                                            ("hopper", 48, 50, 0.5), ("halfcheetah", 24, 50, 0.5),
+                                            ("walker2d", 24, 30, 0.5), ("ant", 20, 50, 0.5), ("cartpole", 64, 50, 0.8)])
+def test_rollout_bitexact_shuffle_fallback(gpu, orc, name, B, H, sigma, monkeypatch):
+    """Every built-in tree fits a DPP family, so the ds_bpermute exchange — the path an arbitrary MJCF tree
+    takes — is forced with MBD_NO_DPP=1 (read when the env is created) and held to the same bit-exact bar."""
+    monkeypatch.setenv("MBD_NO_DPP", "1")
+    _rollout_bitexact(gpu, orc, name, B, H, sigma)
+
+
+def _rollout_bitexact(gpu, orc, name, B, H, sigma):
     from mbd_hip.envs import get_env
     env = get_env(name)
     st = env.reset(gpu.prng_key(3))
