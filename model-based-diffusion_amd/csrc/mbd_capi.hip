@@ -276,6 +276,21 @@ extern "C" const char* mbd_last_error(void) { return g_err.c_str(); }
 extern "C" int mbd_version(void) { return 1; }
 // undocumented probe hook (not in include/mbd_hip.h): per-workgroup start/end ticks of the rollout kernel
 extern "C" int mbd_debug_set_clock_buffer(void* d_buf) { g_dbg_clock = (unsigned long long*)d_buf; return MBD_OK; }
+// undocumented test hook (host logic only, no device needed): the DPP lane layout a model would get.
+// Returns the family index (kDppFamilies) or -1; tab[0..15] lane -> link, tab[16..31] link -> lane.
+extern "C" int mbd_debug_dpp_layout(const mbd_model_t* model, signed char tab[32], int shifts_out[4]) {
+  if (!model || !tab || !shifts_out) return -1;
+  const int lps = model->n_links <= 4 ? 4 : (model->n_links <= 8 ? 8 : 16);
+  const int order16[2] = {0, 3}, order_small[2] = {2, 1};
+  for (int t = 0; t < 2; ++t) {
+    const int fam = lps == 16 ? order16[t] : order_small[t];
+    if (find_dpp_layout(*model, lps, kDppFamilies[fam], tab)) {
+      for (int k = 0; k < 4; ++k) shifts_out[k] = kDppFamilies[fam][k];
+      return fam;
+    }
+  }
+  return -1;
+}
 extern "C" int mbd_device_count(int* count) {
   if (!count) return fail(MBD_ERR_INVALID, "count is NULL");
   *count = device_count_quiet();

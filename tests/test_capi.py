@@ -92,3 +92,27 @@ def test_product_does_not_import_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp")):
                 text = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in text.lower().replace("checker", ""), f"{f} mentions the oracle"
+
+
+def test_dpp_lane_layouts_of_the_builtin_models(lib):
+    """Host logic of the DPP exchange (csrc/mbd_capi.hip::find_dpp_layout): every built-in tree gets a layout in
+    which each link sits on its own lane of the LPS-lane group and every s-th child (in link order) sits exactly
+    shift[s] lanes below its parent — what the kernels' row shifts assume."""
+    lib.mbd_debug_dpp_layout.restype = C.c_int
+    want_family = {"humanoidrun": 0, "humanoidtrack": 0, "humanoidstandup": 0, "walker2d": 1, "halfcheetah": 1,
+                   "hopper": 2, "cartpole": 2, "ant": 3}
+    for name, fam in want_family.items():
+        m = load_model(name)
+        ms = m.to_struct()
+        tab = (C.c_byte * 32)()
+        shifts = (C.c_int * 4)()
+        assert lib.mbd_debug_dpp_layout(C.byref(ms), tab, shifts) == fam, name
+        L, parent = m.fields["n_links"], [int(x) for x in m.fields["parent"]]
+        lps = 4 if L <= 4 else (8 if L <= 8 else 16)
+        lane = [tab[16 + l] for l in range(L)]
+        assert sorted(set(lane)) == sorted(lane) and min(lane) >= 0 and max(lane) < lps, name
+        assert all(tab[lane[l]] == l for l in range(L))
+        assert sum(1 for i in range(16) if tab[i] >= 0) == L
+        for l in range(1, L):
+            slot = sum(1 for c in range(l) if parent[c] == parent[l])
+            assert shifts[slot] != 0 and lane[parent[l]] == lane[l] + shifts[slot], (name, l)
