@@ -241,7 +241,7 @@ __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp,
   auto opq = [](float x) { asm("" : "+v"(x)); return x; };
   float sb = fclip(opq(dot(C.Z, A.X)), -1.0f, 1.0f);
   float cb2 = ffma(-sb, sb, 1.0f);
-  float cb = fsqrt(cb2 < 0.0f ? 0.0f : cb2);
+  float cb = sqrt_flush(cb2);
   float inv = div_(1.0f, cb + 1e-10f);
   const f2 a02 = angle_unit2(mk2(-opq(dot(C.Z, A.Y)) * inv, -opq(dot(C.Y, A.X)) * inv),
                              mk2(opq(dot(C.Z, A.Z)) * inv, opq(dot(C.X, A.X)) * inv));
@@ -821,7 +821,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         if (elast != 0.0f) vn_prev = add(v_old, cross(w_old, rc)).z;
         float vn = vpt.z;
         v3 vt = mk3(vpt.x, vpt.y, 0.0f);
-        float vtn = fsqrt(ffma(vt.x, vt.x, vt.y * vt.y));
+        float vtn = sqrt_flush(ffma(vt.x, vt.x, vt.y * vt.y));
         float inv = div_(1.0f, vtn + 1e-10f);
         v3 dir = mk3(vt.x * inv, vt.y * inv, 0.0f);
         v3 cn = crossz(rc), cdv = cross_bz0(rc, dir);

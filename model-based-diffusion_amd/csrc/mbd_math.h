@@ -198,6 +198,21 @@ __device__ __forceinline__ f2 div2_(f2 n, f2 d) {
   return fma2(e, r, q);
 }
 
+// ---- the solver's square root -----------------------------------------------------------------------------
+// arguments below 1e-30 give 0; above, reciprocal square root + FMA refinement, bit-identical to the correctly
+// rounded sqrtf on every float32 in [1e-30, FLT_MAX] (exhaustive: tools/probes/probe_sqrt.hip).  10 VALU instead
+// of the 16 of the compiler's expansion, which also scales denormal inputs.
+__device__ __forceinline__ float sqrt_flush(float x) {
+  float r = __builtin_amdgcn_rsqf(x);
+  float g = x * r, h = 0.5f * r;
+  float e = ffma(-h, g, 0.5f);
+  g = ffma(g, e, g);
+  h = ffma(h, e, h);
+  float d = ffma(-g, g, x);
+  float s = ffma(d, h, g);
+  return x < 1e-30f ? 0.0f : s;
+}
+
 // two packed divisions as interleaved chains (same arithmetic as two div2_ calls)
 __device__ __forceinline__ void div2x2_(f2 na, f2 da, f2 nb, f2 db, f2& qa_out, f2& qb_out) {
   na = mk2(fabs_(na.x) < 1e-28f ? 0.0f : na.x, fabs_(na.y) < 1e-28f ? 0.0f : na.y);

@@ -107,7 +107,7 @@ static void joint_frames(const mbd_model_t* m, int l, const xf_t* P, const xf_t*
    * reciprocal normalises them and the line of nodes Zc x Xp */
   real sb = sp_clip(sp_dot3(f->Zc, f->Xp), R(-1), R(1));
   real cb2 = sp_fma(-sb, sb, R(1));
-  real cb = sp_sqrt(cb2 < R(0) ? R(0) : cb2);
+  real cb = sp_sqrt_flush(cb2);
   real inv = sp_div(R(1), cb + R(1e-10));
   f->ang[0] = sp_angle_unit(-sp_dot3(f->Zc, f->Yp) * inv, sp_dot3(f->Zc, f->Zp) * inv);
   f->ang[1] = sp_angle_unit(sb, cb);
@@ -401,7 +401,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_cross3(xd_prev[l].w, rc, t); sp_add3(xd_prev[l].v, t, vprev);
     real vn = vpt[2], vn_prev = vprev[2];
     real vt[3] = {vpt[0], vpt[1], R(0)};
-    real vtn = sp_sqrt(sp_fma(vt[0], vt[0], vt[1] * vt[1]));
+    real vtn = sp_sqrt_flush(sp_fma(vt[0], vt[0], vt[1] * vt[1]));
     real inv = sp_div(R(1), vtn + R(1e-10));
     real dir[3], cn[3], icn[3], cdv[3], icd[3];
     sp_set3(dir, vt[0] * inv, vt[1] * inv, R(0));

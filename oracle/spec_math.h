@@ -32,6 +32,11 @@ static inline real sp_fma(real a, real b, real c) {
 static inline real sp_sqrt(real x) {
   return sizeof(real) == 4 ? (real)__builtin_sqrtf((float)x) : (real)__builtin_sqrt((double)x);
 }
+/* the solver's square root (cos of the middle Euler angle, tangential contact speed): arguments below 1e-30
+ * give 0, everything else is the correctly rounded root.  (The flush lets the kernels use the 8-instruction
+ * rsq + FMA sequence, which tools/probes/probe_sqrt.hip shows bit-identical to sqrtf on EVERY float32 in
+ * [1e-30, FLT_MAX], instead of the 16-instruction expansion that also covers denormal inputs.) */
+static inline real sp_sqrt_flush(real x) { return x < R(1e-30) ? R(0) : sp_sqrt(x); }
 static inline real sp_abs(real x) { return sizeof(real) == 4 ? (real)__builtin_fabsf((float)x) : (real)__builtin_fabs((double)x); }
 static inline real sp_min(real a, real b) { return a < b ? a : b; }
 static inline real sp_max(real a, real b) { return a > b ? a : b; }

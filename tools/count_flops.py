@@ -14,7 +14,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_ZN3mbd14rollout_kernelILi16ELb1ELb0ELi3ELi1ELi1ELin4ELin6EEEvNS_13RolloutParamsE"
+KERNEL = "_ZN3mbd14rollout_kernelILi16ELb1ELb0ELi3ELi1ELi1ELin4ELin6ELi0EEEvNS_13RolloutParamsE"
 
 
 def main():
