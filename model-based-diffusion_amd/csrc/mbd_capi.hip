@@ -70,7 +70,7 @@ struct mbd_env {
   float* d_xref = nullptr;
   bool has_xref = false;
   float rew_xref = 0.0f;
-  int lps = 16, max_children = 0, max_col = 0;
+  int lps = 16, max_children = 0, max_col = 0, max_rot = 0;
   bool slides = false;
   bool slide_limits = false;  // any slide dof with a finite range
   // DPP layout (kernels.h "lane exchange without the LDS"): lane <-> link tables when the tree fits the shifts
@@ -147,7 +147,7 @@ int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B
     return MBD_OK;
   }
   RolloutParams P{env->d_model, d_state0, d_us, d_rewss, d_rews, d_xpos, d_state_final, B, H,
-                  env->slide_limits ? 1 : 0, env->max_children, env->d_lane_tab, g_dbg_clock};
+                  env->slide_limits ? 1 : 0, env->max_children, env->max_rot, env->d_lane_tab, g_dbg_clock};
   const bool iso = env->model.iso_inertia != 0;
   const int spw = 64 / env->lps;
   dim3 grid((B + spw - 1) / spw), block(64);
@@ -374,6 +374,7 @@ extern "C" int mbd_env_create_model(const char* env_name, int device, const mbd_
   for (int l = 0; l < m.n_links; ++l) {
     if (m.parent[l] >= 0) nch[m.parent[l]]++;
     if (m.n_slide[l] > 0 || m.n_rot[l] == 0) e->slides = true;  // slides and welds both need the generic kernels
+    if (m.n_rot[l] > e->max_rot) e->max_rot = m.n_rot[l];
     for (int k = 0; k < m.n_slide[l]; ++k)
       if (m.slide_lo[l][k] > -1e8f || m.slide_hi[l][k] < 1e8f) e->slide_limits = true;
   }

@@ -36,6 +36,7 @@ struct RolloutParams {
   int B, H;
   int slide_limits;  // any slide dof with a finite range (wave-uniform: the limit corrections are skipped otherwise)
   int max_children;  // largest child count in the model (wave-uniform bound of the generic kernels' child loops)
+  int max_rot;       // largest number of hinge dofs on one joint (1: hopper, walker2d, halfcheetah, ant, cartpole)
   // DPP instantiations only: lane (within the 16-lane row) <-> link tables, [0..15] lane -> link (-1: padding),
   // [16..31] link -> lane.  Device memory, written by the host when the model's tree fits the shift pattern.
   const signed char* lane_tab;
@@ -222,7 +223,9 @@ struct JointConst {
   q4 ap_rot, ac_rot;
 };
 
-__device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp, q4 Pr, v3 Cp, q4 Cr) {
+// multi (wave-uniform): some joint of the model has more than one hinge dof.  Single-hinge models only ever use
+// the first Euler angle and axis; the other two would be masked to exact zeros downstream.
+__device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp, q4 Pr, v3 Cp, q4 Cr, bool multi) {
   JointFrames f;
   // parent side in the low halves, child side in the high halves of packed pairs
   const q4x2 R2 = pack4(Pr, Cr);
@@ -243,13 +246,20 @@ __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp,
   float cb2 = ffma(-sb, sb, 1.0f);
   float cb = sqrt_flush(cb2);
   float inv = div_(1.0f, cb + 1e-10f);
-  const f2 a02 = angle_unit2(mk2(-opq(dot(C.Z, A.Y)) * inv, -opq(dot(C.Y, A.X)) * inv),
-                             mk2(opq(dot(C.Z, A.Z)) * inv, opq(dot(C.X, A.X)) * inv));
-  f.ang0 = a02.x;
-  f.ang1 = angle_unit(sb, cb);
-  f.ang2 = a02.y;
-  v3 n = cross(C.Z, A.X);
-  f.ax1 = scale(n, inv);
+  if (multi) {
+    const f2 a02 = angle_unit2(mk2(-opq(dot(C.Z, A.Y)) * inv, -opq(dot(C.Y, A.X)) * inv),
+                               mk2(opq(dot(C.Z, A.Z)) * inv, opq(dot(C.X, A.X)) * inv));
+    f.ang0 = a02.x;
+    f.ang1 = angle_unit(sb, cb);
+    f.ang2 = a02.y;
+    v3 n = cross(C.Z, A.X);
+    f.ax1 = scale(n, inv);
+  } else {
+    f.ang0 = angle_unit(-opq(dot(C.Z, A.Y)) * inv, opq(dot(C.Z, A.Z)) * inv);
+    f.ang1 = 0.0f;
+    f.ang2 = 0.0f;
+    f.ax1 = mk3(0.0f, 0.0f, 0.0f);
+  }
   return f;
 }
 
@@ -430,6 +440,8 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
   // the generic kernels (MAXCH = 4) bound their child loops by the model's largest child count: a scalar
   // branch per slot; a skipped slot would have added exact zeros
   const int max_children = P.max_children;
+  // humanoid-shaped instantiations always carry multi-dof joints; the others ask the model (scalar branches)
+  const bool multi = (MAXCH == 3 && !SLIDES) || P.max_rot > 1;
   auto child_slot = [&](int c) { return MAXCH <= 3 || c < max_children; };
   // DPP layout: 0/1 masks — rm[s]: this link has an s-th child (it sits at lane - Ds); pm[s]: this link is the
   // s-th child of its parent (which sits at lane + Ds)
@@ -540,7 +552,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       }
       v3 fc_v, fc_w, fp_v, fp_w;
       {
-        JointFrames f = joint_frames(jc, Pp, Pr, p, r);
+        JointFrames f = joint_frames(jc, Pp, Pr, p, r, multi);
         const WInert2<ISO> W2 = world_inertia2<ISO>(ip, ic, pack4(Pr, r));
         const v3x2 arm = sub2(f.anchor, pack3(Pp, p));                 // (rp, rc)
         shfl_join();
@@ -554,8 +566,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           T = axpy(fk, ax, T);
         };
         torque(0, f.Xp, f.ang0);
-        torque(1, f.ax1, f.ang1);
-        torque(2, f.Zc, f.ang2);
+        if (multi) {
+          torque(1, f.ax1, f.ang1);
+          torque(2, f.Zc, f.ang2);
+        }
         if constexpr (SLIDES) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
@@ -625,7 +639,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       v3 dc_p, dc_th, dp_p, dp_th;
       v3 cp[MAXCH], cth[MAXCH];
       {
-        JointFrames f = joint_frames(jc, Pp, Pr, p, r);
+        JointFrames f = joint_frames(jc, Pp, Pr, p, r, multi);
         v3 d = sub(f.ap, f.ac);
         if constexpr (SLIDES) {
 #pragma unroll
@@ -664,8 +678,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         AngPrep c0, c1, c2_;
         auto limits_prepare = [&] {
           c0 = ang_prepare<ISO>(scale(f.Xp, -viol_of(0, f.ang0)), ip, ic, W2);
-          c1 = ang_prepare<ISO>(scale(f.ax1, -viol_of(1, f.ang1)), ip, ic, W2);
-          c2_ = ang_prepare<ISO>(scale(f.Zc, -viol_of(2, f.ang2)), ip, ic, W2);
+          if (multi) {
+            c1 = ang_prepare<ISO>(scale(f.ax1, -viol_of(1, f.ang1)), ip, ic, W2);
+            c2_ = ang_prepare<ISO>(scale(f.Zc, -viol_of(2, f.ang2)), ip, ic, W2);
+          }
         };
         f2 q_ta, q01;  // (translation, alignment) and (limit 0, limit 1) quotients
         float q2;
@@ -673,8 +689,14 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
           // no exchange latency to hide here: all divisions run as interleaved independent chains (a dependent
           // packed FMA costs a wait state, which the compiler fills with s_nop when nothing else is at hand)
           limits_prepare();
-          div2x2_(mk2(c2, ca.num), mk2(den, ca.den), mk2(c0.num, c1.num), mk2(c0.den, c1.den), q_ta, q01);
-          q2 = div_(c2_.num, c2_.den);
+          if (multi) {
+            div2x2_(mk2(c2, ca.num), mk2(den, ca.den), mk2(c0.num, c1.num), mk2(c0.den, c1.den), q_ta, q01);
+            q2 = div_(c2_.num, c2_.den);
+          } else {
+            q_ta = div2_(mk2(c2, ca.num), mk2(den, ca.den));
+            q01 = mk2(div_(c0.num, c0.den), 0.0f);
+            q2 = 0.0f;
+          }
         } else {
           q_ta = div2_(mk2(c2, ca.num), mk2(den, ca.den));
         }
@@ -717,12 +739,19 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
         ang_apply(ca, q_ta.y, js_ang, dth2);
         if constexpr (!DPP) {  // (the shuffled kernels keep this work behind the translational exchange)
           limits_prepare();
-          q01 = div2_(mk2(c0.num, c1.num), mk2(c0.den, c1.den));
-          q2 = div_(c2_.num, c2_.den);
+          if (multi) {
+            q01 = div2_(mk2(c0.num, c1.num), mk2(c0.den, c1.den));
+            q2 = div_(c2_.num, c2_.den);
+          } else {
+            q01 = mk2(div_(c0.num, c0.den), 0.0f);
+            q2 = 0.0f;
+          }
         }
         ang_apply(c0, q01.x, js_ang, dth2);
-        ang_apply(c1, q01.y, js_ang, dth2);
-        ang_apply(c2_, q2, js_ang, dth2);
+        if (multi) {
+          ang_apply(c1, q01.y, js_ang, dth2);
+          ang_apply(c2_, q2, js_ang, dth2);
+        }
         dc_th = hi3(dth2); dp_th = lo3(dth2);
       }
       {
@@ -848,7 +877,7 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
       v3 Pp = shfl3(p, plane);
       q4 Pr = shfl4(r, plane);
       if (world_parent) { Pp = mk3(0, 0, 0); Pr = q4{1, 0, 0, 0}; }
-      JointFrames f = joint_frames(jc, Pp, Pr, p, r);
+      JointFrames f = joint_frames(jc, Pp, Pr, p, r, multi);
       v3 sx = rot(saxis[0], f.aprot);
       v3 vc = add(v, cross(w, sub(f.ac, p)));  // link 0 hangs off the static world
       float sn, cs;
