@@ -137,6 +137,20 @@ bool find_dpp_layout(const mbd_model_t& m, int lps, const int D[4], signed char 
   return false;
 }
 
+// One launch site for every instantiation.  lds > 0 reserves dynamic LDS the kernel never touches: more than half
+// of a CU's 160 KB keeps a second workgroup — of this or of a concurrent plan's launch — off the CU, so concurrent
+// plans spread over the chip instead of piling onto the CUs the dispatcher fills first (tools/gpu_concurrent.sh).
+template <typename K>
+void launch_rollout_kernel(K kernel, int device, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                           const RolloutParams& P) {
+  static bool raised[16] = {false};  // per instantiation and device: allow > 64 KB of dynamic LDS
+  if (lds > 0 && device >= 0 && device < 16 && !raised[device]) {
+    (void)hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    raised[device] = true;
+  }
+  hipLaunchKernelGGL(kernel, grid, block, lds, stream, P);
+}
+
 int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B, int H, float* d_rewss,
                    float* d_rews, float* d_xpos, float* d_state_final, hipStream_t stream) {
   if (B <= 0 || H <= 0) return fail(MBD_ERR_INVALID, "rollout: B=%d H=%d", B, H);
@@ -150,36 +164,46 @@ int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B
                   env->slide_limits ? 1 : 0, env->max_children, env->max_rot, env->d_lane_tab, g_dbg_clock};
   const bool iso = env->model.iso_inertia != 0;
   const int spw = 64 / env->lps;
-  dim3 grid((B + spw - 1) / spw), block(64);
-#define MBD_LAUNCH(LPS, ISO, SL, CH, COL) \
-  hipLaunchKernelGGL((rollout_kernel<LPS, ISO, SL, CH, COL>), grid, block, 0, stream, P)
+  const int waves = (B + spw - 1) / spw;
+  // Wavefronts per workgroup (they are independent).  Four: the four waves of a workgroup land on the four SIMDs
+  // of one CU, which single-wave workgroups do not achieve once a launch (or several concurrent plans) puts four
+  // waves on a CU — N=4096: 1.29 ms with one wave per workgroup, 0.75 ms with four; N=1024: 0.720 -> 0.710 ms
+  // (tools/gpu_wpb.sh).  MBD_WPB overrides for experiments.
+  int wpb = 4;
+  if (const char* w = std::getenv("MBD_WPB")) wpb = std::atoi(w) == 4 ? 4 : (std::atoi(w) == 2 ? 2 : 1);
+  dim3 grid((waves + wpb - 1) / wpb), block(64 * wpb);
+  // up to one workgroup per CU: keep the CU to that workgroup (see launch_rollout_kernel); above, CUs are shared
+  size_t lds = (wpb == 4 && grid.x <= 256) ? 96 * 1024 : 0;
+  if (const char* r = std::getenv("MBD_LDS_RESERVE")) lds = (size_t)std::atoi(r);
+#define MBD_LAUNCH(...) \
+  launch_rollout_kernel(rollout_kernel<__VA_ARGS__>, env->device, grid, block, lds, stream, P)
   const bool humanoid_shape = env->lps == 16 && iso && !env->slides && env->max_children <= 3;
   const bool dpp_h = env->dpp_family == 0;
   if (humanoid_shape && env->max_col <= 1 && dpp_h) {
-    hipLaunchKernelGGL((rollout_kernel<16, true, false, 3, 1, kDppD0, kDppD1, kDppD2>), grid, block, 0, stream, P);
+    MBD_LAUNCH(16, true, false, 3, 1, kDppD0, kDppD1, kDppD2);
   } else if (humanoid_shape && env->max_col <= 5 && dpp_h) {
-    hipLaunchKernelGGL((rollout_kernel<16, true, false, 3, 5, kDppD0, kDppD1, kDppD2>), grid, block, 0, stream, P);
+    MBD_LAUNCH(16, true, false, 3, 5, kDppD0, kDppD1, kDppD2);
   } else if (humanoid_shape && env->max_col <= 1) {
     MBD_LAUNCH(16, true, false, 3, 1);  // humanoid-like trees that do not fit the DPP shifts
   } else if (humanoid_shape && env->max_col <= 5) {
     MBD_LAUNCH(16, true, false, 3, 5);  // humanoidstandup: up to 5 sphere colliders on one link
   } else if (env->lps == 16 && iso && !env->slides && env->max_col <= 2 && env->dpp_family == 3) {
-    hipLaunchKernelGGL((rollout_kernel<16, true, false, 4, 2, 1, -2, -4, -6>), grid, block, 0, stream, P);  // ant
+    MBD_LAUNCH(16, true, false, 4, 2, 1, -2, -4, -6);  // ant
   } else if (env->lps == 16 && iso && !env->slides && env->max_col <= 2) {
     MBD_LAUNCH(16, true, false, 4, 2);  // ant-like: free root with four legs, no slide / weld joints
   } else if (env->lps == 16) {
     if (iso) MBD_LAUNCH(16, true, true, 4, 2); else MBD_LAUNCH(16, false, true, 4, 2);
   } else if (env->lps == 8 && env->dpp_family == 1) {  // walker2d, halfcheetah
-    if (iso) hipLaunchKernelGGL((rollout_kernel<8, true, true, 4, 2, 1, -3, 0>), grid, block, 0, stream, P);
-    else hipLaunchKernelGGL((rollout_kernel<8, false, true, 4, 2, 1, -3, 0>), grid, block, 0, stream, P);
+    if (iso) MBD_LAUNCH(8, true, true, 4, 2, 1, -3, 0);
+    else MBD_LAUNCH(8, false, true, 4, 2, 1, -3, 0);
   } else if (env->lps == 8 && env->dpp_family == 2) {
-    if (iso) hipLaunchKernelGGL((rollout_kernel<8, true, true, 4, 2, 1, 0, 0>), grid, block, 0, stream, P);
-    else hipLaunchKernelGGL((rollout_kernel<8, false, true, 4, 2, 1, 0, 0>), grid, block, 0, stream, P);
+    if (iso) MBD_LAUNCH(8, true, true, 4, 2, 1, 0, 0);
+    else MBD_LAUNCH(8, false, true, 4, 2, 1, 0, 0);
   } else if (env->lps == 8) {
     if (iso) MBD_LAUNCH(8, true, true, 4, 2); else MBD_LAUNCH(8, false, true, 4, 2);
   } else if (env->dpp_family == 2) {  // hopper, cartpole
-    if (iso) hipLaunchKernelGGL((rollout_kernel<4, true, true, 4, 2, 1, 0, 0>), grid, block, 0, stream, P);
-    else hipLaunchKernelGGL((rollout_kernel<4, false, true, 4, 2, 1, 0, 0>), grid, block, 0, stream, P);
+    if (iso) MBD_LAUNCH(4, true, true, 4, 2, 1, 0, 0);
+    else MBD_LAUNCH(4, false, true, 4, 2, 1, 0, 0);
   } else {
     if (iso) MBD_LAUNCH(4, true, true, 4, 2); else MBD_LAUNCH(4, false, true, 4, 2);
   }

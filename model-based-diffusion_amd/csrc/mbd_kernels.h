@@ -351,7 +351,7 @@ __device__ __forceinline__ v3 iinv_z0(const Inert<ISO>& in, const WInert<ISO>& W
 // slot).  Groups of LPS lanes never straddle a 16-lane DPP row, and the 0/1 masks discard whatever a shift
 // pulls in from a neighbouring candidate of the same row.
 template <int LPS, bool ISO, bool SLIDES, int MAXCH, int MAXCOL, int D0 = 0, int D1 = 0, int D2 = 0, int D3 = 0>
-__global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
+__global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
   constexpr bool DPP = D0 != 0;
   static_assert(!DPP || ((D1 != 0 || D2 == 0) && (D2 != 0 || D3 == 0) && (D3 == 0 || MAXCH >= 4)),
                 "DPP layout: slots are filled in order");
@@ -367,7 +367,10 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
   auto lane_of = [&](int link) { return base + (DPP ? (int)P.lane_tab[16 + link] : link); };
   const bool root_lane = link_ok && l == 0;  // the lane that owns link 0 (rewards, control cost)
   constexpr int SPW = 64 / LPS;
-  const int b_raw = blockIdx.x * SPW + lane / LPS;
+  // a workgroup is 1 or 4 INDEPENDENT wavefronts (no LDS, no barrier): four-wave workgroups are how a launch
+  // of >= 1024 wavefronts gets one wavefront on every SIMD of a CU (dispatch)
+  const int wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int b_raw = wave_id * SPW + lane / LPS;
   const bool b_ok = b_raw < P.B;
   const int b = b_ok ? b_raw : P.B - 1;
   const int H = P.H, Nu = M->n_act, nfr = M->n_frames, K = M->n_track;
@@ -914,9 +917,9 @@ __global__ __launch_bounds__(64) void rollout_kernel(RolloutParams P) {
     for (int k = 0; k < 3; ++k) { u_rot[k] = un_rot[k]; u_sl[k] = un_sl[k]; }
   }  // control steps
   if (P.dbg_clock && lane == 0) {
-    P.dbg_clock[blockIdx.x * 3 + 0] = dbg_t0;
-    P.dbg_clock[blockIdx.x * 3 + 1] = __builtin_amdgcn_s_memtime();
-    P.dbg_clock[blockIdx.x * 3 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |
+    P.dbg_clock[wave_id * 3 + 0] = dbg_t0;
+    P.dbg_clock[wave_id * 3 + 1] = __builtin_amdgcn_s_memtime();
+    P.dbg_clock[wave_id * 3 + 2] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (31 << 11)) |
                                       ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (31 << 11)) << 32);
   }
   if (root_lane && b_ok && P.rews) P.rews[b] = rew_sum / (float)H;
