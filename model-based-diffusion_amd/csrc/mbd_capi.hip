@@ -90,6 +90,10 @@ struct mbd_plan {
   int HNu = 0;
   std::vector<float> alphas, alphas_bar, sigmas;
   hipStream_t stream = nullptr;
+  // sharded plans: the other ranks' candidate rows are sampled on a second stream while the rollout runs
+  hipStream_t aux = nullptr;
+  hipEvent_t ev_in = nullptr, ev_aux = nullptr;
+  bool aux_pending = false;
   float *d_state0 = nullptr, *d_Y0s = nullptr, *d_rewss = nullptr, *d_rews = nullptr, *d_lp = nullptr;
   float *d_xpos = nullptr, *d_weights = nullptr, *d_Ybar = nullptr, *d_mu = nullptr, *d_rewmeans = nullptr;
   float *d_scratch = nullptr;
@@ -597,6 +601,9 @@ extern "C" int mbd_plan_destroy(mbd_plan* p) {
   (void)hipFree(p->d_mu); (void)hipFree(p->d_rewmeans); (void)hipFree(p->d_scratch);
   (void)hipFree(p->d_sigma); (void)hipFree(p->d_spread); (void)hipFree(p->d_idx);
   if (p->stream) (void)hipStreamDestroy(p->stream);
+  if (p->aux) (void)hipStreamDestroy(p->aux);
+  if (p->ev_in) (void)hipEventDestroy(p->ev_in);
+  if (p->ev_aux) (void)hipEventDestroy(p->ev_aux);
   delete p;
   return MBD_OK;
 }
@@ -627,14 +634,41 @@ extern "C" int mbd_plan_sample_rollout(mbd_plan* p, int i, const uint32_t key_sa
   HIP_TRY(hipSetDevice(e->device));
   hipStream_t s = (hipStream_t)stream_;
   const int N = c.Nsample, H = c.Hsample, HNu = p->HNu;
-  // A1: every rank generates ALL N candidate sequences (counter-based noise; microseconds), so that
-  // phase 2 needs no second collective and is bit-identical for every shard layout
+  // A1: every rank generates ALL N candidate sequences (counter-based noise), so that phase 2 needs no second
+  // collective and is bit-identical for every shard layout.  A sharded plan samples its own rows first and the
+  // others' on a second stream, behind the rollout (which leaves three quarters of the CUs idle at 1024
+  // candidates); mbd_plan_score_update joins that stream before it reads them.
   {
-    const uint64_t size = (uint64_t)N * HNu;
-    const uint64_t threads = c.prng_impl == MBD_PRNG_PARTITIONABLE ? size : (size + 1) / 2;
-    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, key_sample[0],
-                       key_sample[1], c.prng_impl, N, HNu, p->sigmas[i],
-                       c.update_method > 0 ? (const float*)p->d_sigma : (const float*)nullptr, d_Ybar_i, p->d_Y0s);
+    auto sample = [&](hipStream_t st, uint64_t e0, uint64_t cnt) {
+      if (cnt == 0) return;
+      const uint64_t size = (uint64_t)N * HNu;
+      const bool pair_blocks = c.prng_impl != MBD_PRNG_PARTITIONABLE && e0 == 0 && cnt == size;
+      const uint64_t threads = pair_blocks ? (size + 1) / 2 : cnt;
+      hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, st, key_sample[0],
+                         key_sample[1], c.prng_impl, N, HNu, (unsigned long long)e0, (unsigned long long)cnt,
+                         p->sigmas[i], c.update_method > 0 ? (const float*)p->d_sigma : (const float*)nullptr,
+                         d_Ybar_i, p->d_Y0s);
+    };
+    const uint64_t own0 = (uint64_t)c.shard_begin * HNu, own1 = own0 + (uint64_t)c.shard_count * HNu;
+    static const bool no_aux = [] { const char* v = std::getenv("MBD_NO_AUX"); return v && v[0] == '1'; }();
+    // worth the two events only when the other ranks' rows dominate (tools/gpu_rank_emu.sh: 8 shards 0.774 ->
+    // 0.762 ms per step, 2 shards 0.736 -> 0.742); MBD_NO_AUX=1 keeps everything on the caller's stream (A/B)
+    if (c.shard_count == N || no_aux || (long long)N < 5LL * c.shard_count) {
+      sample(s, 0, (uint64_t)N * HNu);
+    } else {
+      if (!p->aux) {
+        HIP_TRY(hipStreamCreateWithFlags(&p->aux, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&p->ev_aux, hipEventDisableTiming));
+      }
+      HIP_TRY(hipEventRecord(p->ev_in, s));  // Ybar_i is final and the previous step is done with Y0s
+      HIP_TRY(hipStreamWaitEvent(p->aux, p->ev_in, 0));
+      sample(s, own0, own1 - own0);
+      sample(p->aux, 0, own0);
+      sample(p->aux, own1, (uint64_t)N * HNu - own1);
+      HIP_TRY(hipEventRecord(p->ev_aux, p->aux));
+      p->aux_pending = true;
+    }
     HIP_TRY(hipGetLastError());
   }
   // A2/A3: rollout of the local shard
@@ -679,6 +713,10 @@ extern "C" int mbd_plan_score_update(mbd_plan* p, int i, const uint32_t key_samp
   HIP_TRY(hipSetDevice(p->env->device));
   hipStream_t s = (hipStream_t)stream_;
   const int N = c.Nsample, HNu = p->HNu;
+  if (p->aux_pending) {  // the other ranks' rows of Y0s (sampled behind the rollout)
+    HIP_TRY(hipStreamWaitEvent(s, p->ev_aux, 0));
+    p->aux_pending = false;
+  }
   hipLaunchKernelGGL(score_kernel, dim3(1), dim3(kScoreThreads), sizeof(float) * (size_t)N, s, d_rews_all,
                      c.enable_demo ? d_logpd_all : nullptr, N, p->env->rew_xref, c.temp_sample,
                      c.update_method == 0 ? 1 : 0, p->d_weights, d_rew_mean);

@@ -996,9 +996,12 @@ __global__ __launch_bounds__(64) void car2d_rollout_kernel(Car2dParams P) {
 }
 
 // ---- A1: sampling (mbd_planner.py:103-106) -------------------------------------------------------------
-// Y0s[n][e] for rows [row_begin, row_begin+rows) of the global [N][HNu] tensor. One thread per threefry
-// block: legacy layout pairs element j with j+half (both outputs used); partitionable: one element.
+// Y0s[e] for the flat elements [e_begin, e_begin + e_count) of the global [N][HNu] tensor (a rank's own rows
+// first, the other ranks' rows on a second stream while the rollout runs).  Whole tensor, legacy layout: one
+// thread per threefry block, which pairs element j with j+half (both outputs used).  Otherwise one thread per
+// element (partitionable layout: its own block; legacy layout on a sub-range: the block it belongs to).
 __global__ __launch_bounds__(256) void sample_kernel(uint32_t k0, uint32_t k1, int impl, int N, int HNu,
+                                                      unsigned long long e_begin, unsigned long long e_count,
                                                       float sigma_host, const float* __restrict__ sigma_dev,
                                                       const float* __restrict__ Ybar, float* __restrict__ Y0s) {
   const float sigma = sigma_dev ? *sigma_dev : sigma_host;  // path-integral plans carry sigma on the device
@@ -1006,26 +1009,37 @@ __global__ __launch_bounds__(256) void sample_kernel(uint32_t k0, uint32_t k1, i
   const uint64_t half = (size + 1) / 2;
   const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (impl == 1) {
-    if (tid >= size) return;
+    if (tid >= e_count) return;
+    const uint64_t e = e_begin + tid;
     uint32_t o0, o1;
-    threefry2x32(k0, k1, (uint32_t)(tid >> 32), (uint32_t)tid, o0, o1);
+    threefry2x32(k0, k1, (uint32_t)(e >> 32), (uint32_t)e, o0, o1);
     float eps = bits_to_normal(o0 ^ o1);
-    float y = eps * sigma + Ybar[tid % (uint64_t)HNu];
-    Y0s[tid] = fclip(y, -1.0f, 1.0f);
+    float y = eps * sigma + Ybar[e % (uint64_t)HNu];
+    Y0s[e] = fclip(y, -1.0f, 1.0f);
     return;
   }
-  if (tid >= half) return;
-  const uint64_t j1 = tid + half;
+  if (e_begin == 0 && e_count == size) {
+    if (tid >= half) return;
+    const uint64_t j1 = tid + half;
+    uint32_t o0, o1;
+    threefry2x32(k0, k1, (uint32_t)tid, j1 < size ? (uint32_t)j1 : 0u, o0, o1);
+    {
+      float y = bits_to_normal(o0) * sigma + Ybar[tid % (uint64_t)HNu];
+      Y0s[tid] = fclip(y, -1.0f, 1.0f);
+    }
+    if (j1 < size) {
+      float y = bits_to_normal(o1) * sigma + Ybar[j1 % (uint64_t)HNu];
+      Y0s[j1] = fclip(y, -1.0f, 1.0f);
+    }
+    return;
+  }
+  if (tid >= e_count) return;
+  const uint64_t e = e_begin + tid;
+  const uint64_t j0 = e < half ? e : e - half, j1 = j0 + half;
   uint32_t o0, o1;
-  threefry2x32(k0, k1, (uint32_t)tid, j1 < size ? (uint32_t)j1 : 0u, o0, o1);
-  {
-    float y = bits_to_normal(o0) * sigma + Ybar[tid % (uint64_t)HNu];
-    Y0s[tid] = fclip(y, -1.0f, 1.0f);
-  }
-  if (j1 < size) {
-    float y = bits_to_normal(o1) * sigma + Ybar[j1 % (uint64_t)HNu];
-    Y0s[j1] = fclip(y, -1.0f, 1.0f);
-  }
+  threefry2x32(k0, k1, (uint32_t)j0, j1 < size ? (uint32_t)j1 : 0u, o0, o1);
+  float y = bits_to_normal(e < half ? o0 : o1) * sigma + Ybar[e % (uint64_t)HNu];
+  Y0s[e] = fclip(y, -1.0f, 1.0f);
 }
 
 // ---- A5: demo log-densities ------------------------------------------------------------------------------
