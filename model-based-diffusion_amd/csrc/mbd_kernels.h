@@ -71,14 +71,6 @@ __device__ __forceinline__ float dpp_from(float x) {
   constexpr int ctrl = K > 0 ? 0x100 + K /* row_shl:K */ : 0x110 - K /* row_shr:-K */;
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), ctrl, 0xf, 0xf, true));
 }
-// select-by-mask sum over the three slots: exactly one mask is 1.0f (or none): products and sums are exact
-template <int K0, int K1, int K2>
-__device__ __forceinline__ float dpp_pick(float x, float m0, float m1, float m2) {
-  float r = dpp_from<K0>(x) * m0;
-  r = ffma(dpp_from<K1>(x), m1, r);
-  return ffma(dpp_from<K2>(x), m2, r);
-}
-
 // v_fmac_f32 with a DPP source is not something the compiler forms (it keeps v_mov_b32_dpp + v_fmac_f32), so the
 // accumulating forms are written out.  acc += x(lane i+K) * m is bit-identical to an add when m is 1.0f and a
 // no-op when m is 0.0f.  The leading "s_nop 1" covers the hazard of a DPP read within two wait states of a VALU
