@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -79,6 +80,14 @@ struct mbd_env {
   signed char* d_lane_tab = nullptr;
   // scratch for the single-env step path
   float *d_s_in = nullptr, *d_act = nullptr, *d_s_out = nullptr, *d_rew = nullptr;
+  mbd_env() = default;
+  mbd_env(const mbd_env&) = delete;
+  mbd_env& operator=(const mbd_env&) = delete;
+  ~mbd_env() {  // owns its device buffers: every exit of the create functions, early or not, releases them
+    (void)hipSetDevice(device);
+    (void)hipFree(d_model); (void)hipFree(d_xref); (void)hipFree(d_lane_tab);
+    (void)hipFree(d_s_in); (void)hipFree(d_s_out); (void)hipFree(d_act); (void)hipFree(d_rew);
+  }
   int state_size() const { return kind == ENV_CAR2D ? 3 : model.n_links * MBD_LINK_STATE; }
   int action_size() const { return kind == ENV_CAR2D ? 2 : model.n_act; }
   int observation_size() const { return kind == ENV_CAR2D ? 3 : model.n_q + model.n_qd; }
@@ -102,6 +111,21 @@ struct mbd_plan {
   bool timing = false;
   std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
   size_t events_used = 0;
+  mbd_plan() = default;
+  mbd_plan(const mbd_plan&) = delete;
+  mbd_plan& operator=(const mbd_plan&) = delete;
+  ~mbd_plan() {  // owns its device buffers, streams and events
+    if (env) (void)hipSetDevice(env->device);
+    for (auto& ev : events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
+    (void)hipFree(d_state0); (void)hipFree(d_Y0s); (void)hipFree(d_rewss); (void)hipFree(d_rews);
+    (void)hipFree(d_lp); (void)hipFree(d_xpos); (void)hipFree(d_weights); (void)hipFree(d_Ybar);
+    (void)hipFree(d_mu); (void)hipFree(d_rewmeans); (void)hipFree(d_scratch);
+    (void)hipFree(d_sigma); (void)hipFree(d_spread); (void)hipFree(d_idx);
+    if (stream) (void)hipStreamDestroy(stream);
+    if (aux) (void)hipStreamDestroy(aux);
+    if (ev_in) (void)hipEventDestroy(ev_in);
+    if (ev_aux) (void)hipEventDestroy(ev_aux);
+  }
 };
 
 namespace {
@@ -356,7 +380,8 @@ extern "C" int mbd_env_create_car2d(int device, const float* xref, mbd_env** out
   if (n == 0) return fail(MBD_ERR_NO_DEVICE, "no gfx950 device visible (libmbd_hip has no CPU fallback)");
   if (device < 0 || device >= n) return fail(MBD_ERR_INVALID, "device %d of %d", device, n);
   HIP_TRY(hipSetDevice(device));
-  mbd_env* e = new mbd_env();
+  std::unique_ptr<mbd_env> guard(new mbd_env());
+  mbd_env* e = guard.get();
   e->kind = ENV_CAR2D;
   e->device = device;
   e->name = "car2d";
@@ -377,8 +402,8 @@ extern "C" int mbd_env_create_car2d(int device, const float* xref, mbd_env** out
     e->rew_xref = s / 50.0f;
   }
   int rc = env_common_init(e);
-  if (rc != MBD_OK) { delete e; return rc; }
-  *out = e;
+  if (rc != MBD_OK) return rc;
+  *out = guard.release();
   return MBD_OK;
 }
 
@@ -391,7 +416,8 @@ extern "C" int mbd_env_create_model(const char* env_name, int device, const mbd_
   if (n == 0) return fail(MBD_ERR_NO_DEVICE, "no gfx950 device visible (libmbd_hip has no CPU fallback)");
   if (device < 0 || device >= n) return fail(MBD_ERR_INVALID, "device %d of %d", device, n);
   HIP_TRY(hipSetDevice(device));
-  mbd_env* e = new mbd_env();
+  std::unique_ptr<mbd_env> guard(new mbd_env());
+  mbd_env* e = guard.get();
   e->kind = ENV_MODEL;
   e->device = device;
   e->name = env_name;
@@ -411,12 +437,11 @@ extern "C" int mbd_env_create_model(const char* env_name, int device, const mbd_
     if (nch[l] > e->max_children) e->max_children = nch[l];
     if (ncl[l] > e->max_col) e->max_col = ncl[l];
   }
-  if (e->max_children > kMaxChildren) { delete e; return fail(MBD_ERR_UNSUPPORTED, "a link has %d children > %d", e->max_children, kMaxChildren); }
+  if (e->max_children > kMaxChildren) { return fail(MBD_ERR_UNSUPPORTED, "a link has %d children > %d", e->max_children, kMaxChildren); }
   {
     const bool standup_shape = e->lps == 16 && m.iso_inertia && !e->slides && e->max_children <= 3;
     if (e->max_col > (standup_shape ? 5 : 2)) {
       const int mc = e->max_col;
-      delete e;
       return fail(MBD_ERR_UNSUPPORTED, "a link has %d sphere colliders: more than this kernel family is built for", mc);
     }
   }
@@ -438,7 +463,7 @@ extern "C" int mbd_env_create_model(const char* env_name, int device, const mbd_
   HIP_TRY(hipMalloc(&e->d_model, sizeof(mbd_model_t)));
   HIP_TRY(hipMemcpy(e->d_model, &e->model, sizeof(mbd_model_t), hipMemcpyHostToDevice));
   if (xref) {
-    if (m.n_track < 1) { delete e; return fail(MBD_ERR_INVALID, "xref given but n_track = 0"); }
+    if (m.n_track < 1) return fail(MBD_ERR_INVALID, "xref given but n_track = 0");
     const size_t nb = sizeof(float) * (size_t)m.n_track * 50 * 3;
     HIP_TRY(hipMalloc(&e->d_xref, nb));
     HIP_TRY(hipMemcpy(e->d_xref, xref, nb, hipMemcpyHostToDevice));
@@ -446,17 +471,13 @@ extern "C" int mbd_env_create_model(const char* env_name, int device, const mbd_
   }
   e->rew_xref = rew_xref;
   rc = env_common_init(e);
-  if (rc != MBD_OK) { delete e; return rc; }
-  *out = e;
+  if (rc != MBD_OK) return rc;
+  *out = guard.release();
   return MBD_OK;
 }
 
 extern "C" int mbd_env_destroy(mbd_env* e) {
-  if (!e) return MBD_OK;
-  (void)hipSetDevice(e->device);
-  (void)hipFree(e->d_model); (void)hipFree(e->d_xref); (void)hipFree(e->d_lane_tab);
-  (void)hipFree(e->d_s_in); (void)hipFree(e->d_s_out); (void)hipFree(e->d_act); (void)hipFree(e->d_rew);
-  delete e;
+  delete e;  // (nullptr is fine)
   return MBD_OK;
 }
 
@@ -562,7 +583,8 @@ extern "C" int mbd_plan_create(mbd_env* env, const mbd_plan_config* cfg, mbd_pla
   }
   if ((size_t)cfg->Nsample * sizeof(float) > 160 * 1024 - 1024) return fail(MBD_ERR_UNSUPPORTED, "Nsample too large for the LDS-resident score kernel");
   HIP_TRY(hipSetDevice(env->device));
-  mbd_plan* p = new mbd_plan();
+  std::unique_ptr<mbd_plan> guard(new mbd_plan());
+  mbd_plan* p = guard.get();
   p->env = env;
   p->cfg = *cfg;
   const int N = cfg->Nsample, H = cfg->Hsample, Nu = env->action_size(), Nd = cfg->Ndiffuse, sh = cfg->shard_count;
@@ -588,23 +610,12 @@ extern "C" int mbd_plan_create(mbd_env* env, const mbd_plan_config* cfg, mbd_pla
     const float one = 1.0f;  // path_integral.py:131
     HIP_TRY(hipMemcpy(p->d_sigma, &one, sizeof(float), hipMemcpyHostToDevice));
   }
-  *out = p;
+  *out = guard.release();
   return MBD_OK;
 }
 
 extern "C" int mbd_plan_destroy(mbd_plan* p) {
-  if (!p) return MBD_OK;
-  (void)hipSetDevice(p->env->device);
-  for (auto& ev : p->events) { (void)hipEventDestroy(ev.first); (void)hipEventDestroy(ev.second); }
-  (void)hipFree(p->d_state0); (void)hipFree(p->d_Y0s); (void)hipFree(p->d_rewss); (void)hipFree(p->d_rews);
-  (void)hipFree(p->d_lp); (void)hipFree(p->d_xpos); (void)hipFree(p->d_weights); (void)hipFree(p->d_Ybar);
-  (void)hipFree(p->d_mu); (void)hipFree(p->d_rewmeans); (void)hipFree(p->d_scratch);
-  (void)hipFree(p->d_sigma); (void)hipFree(p->d_spread); (void)hipFree(p->d_idx);
-  if (p->stream) (void)hipStreamDestroy(p->stream);
-  if (p->aux) (void)hipStreamDestroy(p->aux);
-  if (p->ev_in) (void)hipEventDestroy(p->ev_in);
-  if (p->ev_aux) (void)hipEventDestroy(p->ev_aux);
-  delete p;
+  delete p;  // (nullptr is fine)
   return MBD_OK;
 }
 
