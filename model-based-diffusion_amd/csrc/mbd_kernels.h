@@ -665,9 +665,8 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         const AngPrep ca = ang_prepare<ISO>(e, ip, ic, W2);
         // joint limits on the Euler angles: three more corrections. Their quotients (0,1) share a packed
         // division, 2 goes alone.
-        auto viol_of = [&](int k, float a) {  // both differences first: selects, not branches
-          const float dlo = a - lim_lo[k], dhi = a - lim_hi[k];
-          float viol = a < lim_lo[k] ? dlo : (a > lim_hi[k] ? dhi : 0.0f);
+        auto viol_of = [&](int k, float a) {  // a - clamp(a, lo, hi): a-lo below, a-hi above, 0 inside
+          const float viol = a - fclip(a, lim_lo[k], lim_hi[k]);
           return k < nr_eff ? viol : 0.0f;
         };
         AngPrep c0, c1, c2_;
@@ -707,7 +706,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           for (int k = 0; k < 3; ++k) {
             v3 sx = rot(saxis[k], f.aprot);
             float qs = dot(sub(f.ac, f.ap), sx);
-            float viol = qs < sl_lo[k] ? qs - sl_lo[k] : (qs > sl_hi[k] ? qs - sl_hi[k] : 0.0f);
+            float viol = qs - fclip(qs, sl_lo[k], sl_hi[k]);
             viol = k < ns ? viol : 0.0f;
             v3 dl = scale(sx, -viol);
             float l2 = dot(dl, dl);

@@ -26,7 +26,14 @@ MBD_HD float fsqrt(float x) { return __builtin_sqrtf(x); }
 MBD_HD float fabs_(float x) { return __builtin_fabsf(x); }
 MBD_HD float fmin_(float a, float b) { return a < b ? a : b; }
 MBD_HD float fmax_(float a, float b) { return a > b ? a : b; }
-MBD_HD float fclip(float v, float lo, float hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// clamp to [lo, hi], lo <= hi, finite arguments: one v_med3_f32 on the device (same value as the two selects)
+MBD_HD float fclip(float v, float lo, float hi) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_amdgcn_fmed3f(v, lo, hi);
+#else
+  return v < lo ? lo : (v > hi ? hi : v);
+#endif
+}
 
 MBD_HD v3 mk3(float x, float y, float z) { return v3{x, y, z}; }
 MBD_HD float dot(v3 a, v3 b) { return ffma(a.x, b.x, ffma(a.y, b.y, a.z * b.z)); }
