@@ -24,8 +24,21 @@ struct q4 {
 MBD_HD float ffma(float a, float b, float c) { return __builtin_fmaf(a, b, c); }
 MBD_HD float fsqrt(float x) { return __builtin_sqrtf(x); }
 MBD_HD float fabs_(float x) { return __builtin_fabsf(x); }
-MBD_HD float fmin_(float a, float b) { return a < b ? a : b; }
-MBD_HD float fmax_(float a, float b) { return a > b ? a : b; }
+// finite arguments: one v_min_f32 / v_max_f32 on the device (same value as the select)
+MBD_HD float fmin_(float a, float b) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_fminf(a, b);
+#else
+  return a < b ? a : b;
+#endif
+}
+MBD_HD float fmax_(float a, float b) {
+#ifdef __HIP_DEVICE_COMPILE__
+  return __builtin_fmaxf(a, b);
+#else
+  return a > b ? a : b;
+#endif
+}
 // clamp to [lo, hi], lo <= hi, finite arguments: one v_med3_f32 on the device (same value as the two selects)
 MBD_HD float fclip(float v, float lo, float hi) {
 #ifdef __HIP_DEVICE_COMPILE__
@@ -240,7 +253,7 @@ __device__ __forceinline__ void div2x2_(f2 na, f2 da, f2 nb, f2 db, f2& qa_out, 
 MBD_HD float angle_unit(float s, float c) {
   float as = fabs_(s), ac = fabs_(c);
   bool swap = as > ac;
-  float u = swap ? ac : as;
+  float u = fmin_(as, ac);
   float z = u * u;
   float p = 0.11199134588241577f;
   p = ffma(p, z, -0.09445883333683014f);
@@ -258,7 +271,7 @@ MBD_HD float angle_unit(float s, float c) {
 __device__ __forceinline__ f2 angle_unit2(f2 s, f2 c) {
   f2 as = __builtin_elementwise_abs(s), ac = __builtin_elementwise_abs(c);
   bool sw0 = as.x > ac.x, sw1 = as.y > ac.y;
-  f2 u = mk2(sw0 ? ac.x : as.x, sw1 ? ac.y : as.y);
+  f2 u = mk2(fmin_(as.x, ac.x), fmin_(as.y, ac.y));
   f2 z = u * u;
   f2 p = mk2(0.11199134588241577f, 0.11199134588241577f);
   p = fma2(p, z, mk2(-0.09445883333683014f, -0.09445883333683014f));
