@@ -242,7 +242,7 @@ __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp,
     const f2 a02 = angle_unit2(mk2(-opq(dot(C.Z, A.Y)) * inv, -opq(dot(C.Y, A.X)) * inv),
                                mk2(opq(dot(C.Z, A.Z)) * inv, opq(dot(C.X, A.X)) * inv));
     f.ang0 = a02.x;
-    f.ang1 = angle_unit(sb, cb);
+    f.ang1 = angle_unit_cpos(sb, cb);
     f.ang2 = a02.y;
     v3 n = cross(C.Z, A.X);
     f.ax1 = scale(n, inv);
@@ -416,6 +416,15 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
       if (s == 3 + k) { act_sl[k] = a; gear_sl[k] = M->act_gear[a]; alo_sl[k] = M->act_lo[a]; ahi_sl[k] = M->act_hi[a]; }
     }
   }
+  // Hinge slots a joint does not have (k >= n_rot; every slot of a free root or a padding lane) are masked in
+  // the CONSTANTS, once: zero spring, damping and gear make the slot's torque an exact zero, limits at +-FLT_MAX
+  // make its violation a - clamp(a) = 0 — no per-substep selects.
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const bool has = k < nr_eff;
+    stiff[k] = has ? stiff[k] : 0.0f; damp[k] = has ? damp[k] : 0.0f; gear_rot[k] = has ? gear_rot[k] : 0.0f;
+    lim_lo[k] = has ? lim_lo[k] : -3.0e38f; lim_hi[k] = has ? lim_hi[k] : 3.0e38f;
+  }
   int child_lane[MAXCH];
   {
     int nc = 0;
@@ -556,8 +565,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         v3 T = mk3(0, 0, 0), F = mk3(0, 0, 0);
         auto torque = [&](int k, v3 ax, float ang) {
           float qdk = dot(rel_w, ax);
-          float fk = ffma(-stiff[k], ang, ffma(-damp[k], qdk, tau[k]));
-          fk = k < nr_eff ? fk : 0.0f;
+          float fk = ffma(-stiff[k], ang, ffma(-damp[k], qdk, tau[k]));  // (0 for a slot the joint lacks)
           T = axpy(fk, ax, T);
         };
         torque(0, f.Xp, f.ang0);
@@ -665,10 +673,8 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         const AngPrep ca = ang_prepare<ISO>(e, ip, ic, W2);
         // joint limits on the Euler angles: three more corrections. Their quotients (0,1) share a packed
         // division, 2 goes alone.
-        auto viol_of = [&](int k, float a) {  // a - clamp(a, lo, hi): a-lo below, a-hi above, 0 inside
-          const float viol = a - fclip(a, lim_lo[k], lim_hi[k]);
-          return k < nr_eff ? viol : 0.0f;
-        };
+        // a - clamp(a, lo, hi): a-lo below, a-hi above, 0 inside (and for a slot the joint lacks)
+        auto viol_of = [&](int k, float a) { return a - fclip(a, lim_lo[k], lim_hi[k]); };
         AngPrep c0, c1, c2_;
         auto limits_prepare = [&] {
           c0 = ang_prepare<ISO>(scale(f.Xp, -viol_of(0, f.ang0)), ip, ic, W2);

@@ -267,6 +267,23 @@ MBD_HD float angle_unit(float s, float c) {
   r = c < 0.0f ? 3.14159265358979323846f - r : r;
   return s < 0.0f ? -r : r;
 }
+// the same for c >= 0 (the middle Euler angle: c = cos b is a square root): no reflection about pi/2
+MBD_HD float angle_unit_cpos(float s, float c) {
+  float as = fabs_(s);
+  bool swap = as > c;
+  float u = fmin_(as, c);
+  float z = u * u;
+  float p = 0.11199134588241577f;
+  p = ffma(p, z, -0.09445883333683014f);
+  p = ffma(p, z, 0.07875244319438934f);
+  p = ffma(p, z, 0.015578965656459332f);
+  p = ffma(p, z, 0.04668578505516052f);
+  p = ffma(p, z, 0.07486556470394135f);
+  p = ffma(p, z, 0.16666975617408752f);
+  float r = ffma(p * z, u, u);
+  r = swap ? 1.57079632679489661923f - r : r;
+  return s < 0.0f ? -r : r;
+}
 // two angle_unit() evaluations at once (the polynomial runs on packed pairs)
 __device__ __forceinline__ f2 angle_unit2(f2 s, f2 c) {
   f2 as = __builtin_elementwise_abs(s), ac = __builtin_elementwise_abs(c);
