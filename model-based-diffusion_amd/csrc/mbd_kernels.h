@@ -424,6 +424,10 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
     const bool has = k < nr_eff;
     stiff[k] = has ? stiff[k] : 0.0f; damp[k] = has ? damp[k] : 0.0f; gear_rot[k] = has ? gear_rot[k] : 0.0f;
     lim_lo[k] = has ? lim_lo[k] : -3.0e38f; lim_hi[k] = has ? lim_hi[k] : 3.0e38f;
+    // slide slots likewise: a zero axis makes the slot's velocity, force, projection and limit terms exact zeros
+    const bool has_sl = is_joint && k < ns;
+    saxis[k] = sel3(has_sl, saxis[k], mk3(0.0f, 0.0f, 0.0f));
+    gear_sl[k] = has_sl ? gear_sl[k] : 0.0f;
   }
   int child_lane[MAXCH];
   {
@@ -485,6 +489,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
     if (M->track_link[k] == l && link_ok) track_k = k;
   const v3 com = mk3(M->com[l][0], M->com[l][1], M->com[l][2]);
   const float dt = M->dt, inv_dt = 1.0f / M->dt, vel_fac = M->vel_fac, ang_fac = M->ang_fac;
+  const float two_inv_dt = 2.0f * inv_dt;
   const float js_pos = is_joint ? M->joint_scale_pos : 0.0f, js_ang = is_joint ? M->joint_scale_ang : 0.0f;
   const float coll_scale = M->collide_scale, invm_sum = ip.inv_mass + ic.inv_mass;
   const float mu = M->friction, elast = M->elasticity;
@@ -579,8 +584,8 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
             v3 s = rot(saxis[k], f.aprot);
             float vs = dot(rel_v, s);
             float fk = ffma(-sl_damp[k], vs, tau_sl[k]);  // motor + MJCF joint damping of the slide dof
-            F = axpy(k < ns && is_joint ? fk : 0.0f, s, F);
-            rel_v = axpy(k < ns ? -vs : 0.0f, s, rel_v);
+            F = axpy(fk, s, F);  // (s = 0 for a slot the joint lacks)
+            rel_v = axpy(-vs, s, rel_v);
           }
         }
         T = axpy(-ang_damp, rel_w, T);
@@ -648,7 +653,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
 #pragma unroll
           for (int k = 0; k < 3; ++k) {
             v3 s = rot(saxis[k], f.aprot);
-            float cf = k < ns ? -dot(d, s) : 0.0f;
+            float cf = -dot(d, s);
             d = axpy(cf, s, d);
           }
         }
@@ -713,7 +718,6 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
             v3 sx = rot(saxis[k], f.aprot);
             float qs = dot(sub(f.ac, f.ap), sx);
             float viol = qs - fclip(qs, sl_lo[k], sl_hi[k]);
-            viol = k < ns ? viol : 0.0f;
             v3 dl = scale(sx, -viol);
             float l2 = dot(dl, dl);
             const v3x2 dl2 = bcast3(dl);
@@ -835,7 +839,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
       v = mk3((p.x - p_prev.x) * inv_dt, (p.y - p_prev.y) * inv_dt, (p.z - p_prev.z) * inv_dt);
       {
         q4 dq = qmul(r, conj(r_prev));
-        float s = (dq.w < 0.0f ? -2.0f : 2.0f) * inv_dt;
+        float s = dq.w < 0.0f ? -two_inv_dt : two_inv_dt;
         w = mk3(dq.x * s, dq.y * s, dq.z * s);
       }
       // ---- (6) collisions.resolve_velocity --------------------------------------------------------------
