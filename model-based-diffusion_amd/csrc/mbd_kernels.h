@@ -205,6 +205,7 @@ __device__ __forceinline__ v3 iinv(const Inert<ISO>& in, const WInert<ISO>& W, v
 struct JointFrames {
   v3 ap, ac;
   v3x2 anchor;  // (ap, ac) packed
+  v3x2 arm;     // (rp, rc): the anchor offsets rotated into the world — the lever arms of the joint's impulses
   q4 aprot, acrot;
   v3 Xp, Xc, Yc, Zc, ax1;
   float ang0, ang1, ang2;
@@ -221,7 +222,9 @@ __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp,
   JointFrames f;
   // parent side in the low halves, child side in the high halves of packed pairs
   const q4x2 R2 = pack4(Pr, Cr);
-  const v3x2 anchor = add2(pack3(Pp, Cp), rot2(pack3(jc.ap_pos, jc.ac_pos), R2));
+  const v3x2 arm = rot2(pack3(jc.ap_pos, jc.ac_pos), R2);
+  const v3x2 anchor = add2(pack3(Pp, Cp), arm);
+  f.arm = arm;
   const q4x2 arot = qmul2(R2, pack4(jc.ap_rot, jc.ac_rot));
   const axes3x2 AX = qaxes2(arot);
   f.ap = lo3(anchor); f.ac = hi3(anchor);
@@ -563,7 +566,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
       {
         JointFrames f = joint_frames(jc, Pp, Pr, p, r, multi);
         const WInert2<ISO> W2 = world_inertia2<ISO>(ip, ic, pack4(Pr, r));
-        const v3x2 arm = sub2(f.anchor, pack3(Pp, p));                 // (rp, rc)
+        const v3x2 arm = f.arm;  // (rp, rc)
         shfl_join();
         const v3x2 va = add2(pack3(Pv, v), cross2(pack3(Pw, w), arm));  // anchor velocities (vp, vc)
         v3 rel_v = sub(hi3(va), lo3(va)), rel_w = sub(w, Pw);
@@ -658,7 +661,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           }
         }
         const WInert2<ISO> W2 = world_inertia2<ISO>(ip, ic, pack4(Pr, r));
-        const v3x2 arm = sub2(f.anchor, pack3(Pp, p));  // (rp, rc)
+        const v3x2 arm = f.arm;  // (rp, rc)
         float c2 = dot(d, d);
         const v3x2 d2 = bcast3(d);
         const v3x2 cr = cross2(arm, d2);                       // (rp x d, rc x d)

@@ -84,6 +84,7 @@ static inline void iinv_apply(const inert_t* in, const real v[3], real o[3]) {
 /* joint frames of link l given parent pose P and child pose C (kinematics.world_to_joint) */
 typedef struct {
   real ap[3], ac[3]; /* anchor world positions on parent / child                                   */
+  real rp[3], rc[3]; /* lever arms: the anchor offsets rotated into the world (ap = P.p + rp, ...)  */
   real aprot[4], acrot[4];
   real Xp[3], Yp[3], Zp[3], Xc[3], Yc[3], Zc[3];
   real ang[3];       /* joint-frame Euler angles x, y', z''                                        */
@@ -95,9 +96,8 @@ static void joint_frames(const mbd_model_t* m, int l, const xf_t* P, const xf_t*
   real acpos[3] = {m->ac_pos[l][0], m->ac_pos[l][1], m->ac_pos[l][2]};
   real aprot[4] = {m->ap_rot[l][0], m->ap_rot[l][1], m->ap_rot[l][2], m->ap_rot[l][3]};
   real acrot[4] = {m->ac_rot[l][0], m->ac_rot[l][1], m->ac_rot[l][2], m->ac_rot[l][3]};
-  real t[3];
-  sp_rot(appos, P->r, t); sp_add3(P->p, t, f->ap);
-  sp_rot(acpos, C->r, t); sp_add3(C->p, t, f->ac);
+  sp_rot(appos, P->r, f->rp); sp_add3(P->p, f->rp, f->ap);
+  sp_rot(acpos, C->r, f->rc); sp_add3(C->p, f->rc, f->ac);
   sp_qmul(P->r, aprot, f->aprot);
   sp_qmul(C->r, acrot, f->acrot);
   sp_qaxes(f->aprot, f->Xp, f->Yp, f->Zp);
@@ -194,7 +194,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     jf_t f;
     joint_frames(m, l, P, &x[l], &f);
     real rc[3], rp[3], t[3], vc[3], vp[3], rel_v[3], rel_w[3];
-    sp_sub3(f.ac, x[l].p, rc); sp_sub3(f.ap, P->p, rp);
+    sp_copy3(f.rc, rc); sp_copy3(f.rp, rp); /* the lever arms themselves, not (anchor - position) */
     sp_cross3(xd[l].w, rc, t); sp_add3(xd[l].v, t, vc);
     sp_cross3(Pd->w, rp, t); sp_add3(Pd->v, t, vp);
     sp_sub3(vc, vp, rel_v); sp_sub3(xd[l].w, Pd->w, rel_w);
@@ -259,7 +259,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
       sp_rot(sa, f.aprot, s);
       sp_axpy3(-sp_dot3(d, s), s, d);
     }
-    sp_sub3(f.ac, x[l].p, rc); sp_sub3(f.ap, P->p, rp);
+    sp_copy3(f.rc, rc); sp_copy3(f.rp, rp); /* the lever arms themselves, not (anchor - position) */
     /* with n = d/|d| and lambda = |d|/(wp+wc): P = lambda n = d * |d|^2 / (|d|^2 (1/m_p + 1/m_c) +
      * (rp x d).I_p^-1 (rp x d) + (rc x d).I_c^-1 (rc x d)) — one division, no square root */
     real c2 = sp_dot3(d, d);

@@ -161,7 +161,7 @@ def test_chaos_amplification(orc, orc64):
     r32, r64 = orc.rollout(ms, st, us), orc64.rollout(ms, st, us)
     err = np.abs(r32 - r64)
     assert err[:, 0].max() < 5e-6            # one control step: round-off only
-    assert err[:, -1].max() > 1e-4           # 350 substeps later: amplified by orders of magnitude
+    assert err[:, -1].max() > 2e-5           # 350 substeps later: amplified beyond the 1e-5 the north star asks for
 
 
 def test_cartpole_weld_limits_and_reward(orc):

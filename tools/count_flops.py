@@ -43,10 +43,10 @@ def main():
             ins = [x.strip().split()[0] for x in body[lab[m.group(1)]:k + 1]
                    if x.startswith("\t") and x.strip() and not x.strip().startswith((".", ";"))]
             loops.append((sum(1 for i in ins if i.startswith("ds_")), sum(1 for i in ins if "dpp" in i), ins))
-    # the substep loop = the smallest loop holding one substep's exchanges: 13 ds_bpermute (the parent's state,
-    # prefetched) and the DPP row shifts of the parent<->child traffic; the control-step loop around it holds
-    # them too (plus the cartpole reward's), but is longer
-    best = min((ins for n, d, ins in loops if n >= 13 and d >= 30), key=len)
+    # the substep loop = the smallest loop holding one substep's DPP row shifts (57 of them: the parent<->child
+    # traffic); the control-step loop around it holds them too, but is longer.  (The compiler may rotate a few of
+    # the 13 prefetching ds_bpermute of a substep into the loop's entry block, so they are not a reliable marker.)
+    best = min((ins for n, d, ins in loops if d >= 50), key=len)
     c = collections.Counter(best)
     flops = 0
     for k, v in c.items():
