@@ -419,15 +419,12 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
       if (s == 3 + k) { act_sl[k] = a; gear_sl[k] = M->act_gear[a]; alo_sl[k] = M->act_lo[a]; ahi_sl[k] = M->act_hi[a]; }
     }
   }
-  // Hinge slots a joint does not have (k >= n_rot; every slot of a free root or a padding lane) are masked in
-  // the CONSTANTS, once: zero spring, damping and gear make the slot's torque an exact zero, limits at +-FLT_MAX
-  // make its violation a - clamp(a) = 0 — no per-substep selects.
+  // Slide slots a joint does not have are masked in the CONSTANTS, once: a zero axis makes the slot's velocity,
+  // force, projection and limit terms exact zeros (everything it multiplies is finite).  Hinge slots are NOT
+  // masked that way: the Euler angles of a slot the joint lacks are meaningless and can overflow near the gimbal
+  // singularity, so they are discarded by selects (0 * inf would be NaN).
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const bool has = k < nr_eff;
-    stiff[k] = has ? stiff[k] : 0.0f; damp[k] = has ? damp[k] : 0.0f; gear_rot[k] = has ? gear_rot[k] : 0.0f;
-    lim_lo[k] = has ? lim_lo[k] : -3.0e38f; lim_hi[k] = has ? lim_hi[k] : 3.0e38f;
-    // slide slots likewise: a zero axis makes the slot's velocity, force, projection and limit terms exact zeros
     const bool has_sl = is_joint && k < ns;
     saxis[k] = sel3(has_sl, saxis[k], mk3(0.0f, 0.0f, 0.0f));
     gear_sl[k] = has_sl ? gear_sl[k] : 0.0f;
@@ -495,6 +492,13 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
   const float two_inv_dt = 2.0f * inv_dt;
   const float js_pos = is_joint ? M->joint_scale_pos : 0.0f, js_ang = is_joint ? M->joint_scale_ang : 0.0f;
   const float coll_scale = M->collide_scale, invm_sum = ip.inv_mass + ic.inv_mass;
+  // isotropic models: the shares of an angular correction, (-ib_p, ib_c)/(ib_p + ib_c) * joint_scale_ang
+  // (zero on non-joint lanes through js_ang)
+  f2 kang2 = mk2(0.0f, 0.0f);
+  if constexpr (ISO) {
+    const float ibs = ip.ib[0] + ic.ib[0];
+    kang2 = mk2(-((ip.ib[0] / ibs) * js_ang), (ic.ib[0] / ibs) * js_ang);
+  }
   const float mu = M->friction, elast = M->elasticity;
   const v3 grav = mk3(M->gravity[0], M->gravity[1], M->gravity[2]);
   const int rkind = M->reward_kind;
@@ -573,7 +577,8 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         v3 T = mk3(0, 0, 0), F = mk3(0, 0, 0);
         auto torque = [&](int k, v3 ax, float ang) {
           float qdk = dot(rel_w, ax);
-          float fk = ffma(-stiff[k], ang, ffma(-damp[k], qdk, tau[k]));  // (0 for a slot the joint lacks)
+          float fk = ffma(-stiff[k], ang, ffma(-damp[k], qdk, tau[k]));
+          fk = k < nr_eff ? fk : 0.0f;  // (a select: ang is garbage, possibly non-finite, for a slot the joint lacks)
           T = axpy(fk, ax, T);
         };
         torque(0, f.Xp, f.ang0);
@@ -678,12 +683,14 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           float sg = qe.w < 0.0f ? -2.0f : 2.0f;
           e = sel3(nr_eff == 0, mk3(sg * qe.x, sg * qe.y, sg * qe.z), e);
         }
-        const AngPrep ca = ang_prepare<ISO>(e, ip, ic, W2);
-        // joint limits on the Euler angles: three more corrections. Their quotients (0,1) share a packed
-        // division, 2 goes alone.
-        // a - clamp(a, lo, hi): a-lo below, a-hi above, 0 inside (and for a slot the joint lacks)
-        auto viol_of = [&](int k, float a) { return a - fclip(a, lim_lo[k], lim_hi[k]); };
-        AngPrep c0, c1, c2_;
+        // a - clamp(a, lo, hi): a-lo below, a-hi above, 0 inside; a select discards the slots the joint lacks
+        auto viol_of = [&](int k, float a) { return k < nr_eff ? a - fclip(a, lim_lo[k], lim_hi[k]) : 0.0f; };
+        // Angular corrections (alignment + up to three Euler-angle limits).  Anisotropic inertia: one
+        // I^-1 e |e|^2 / (e.I_p^-1 e + e.I_c^-1 e) each (quotients (0,1) share a packed division, 2 goes alone).
+        // Isotropic inertia ib*Id: that expression is e * ib_c/(ib_p + ib_c) — linear in e — so the errors are
+        // summed first and applied once with the per-lane constants kang2 = (-k_p, k_c): no division at all.
+        AngPrep ca, c0, c1, c2_;
+        v3 E = e;
         auto limits_prepare = [&] {
           c0 = ang_prepare<ISO>(scale(f.Xp, -viol_of(0, f.ang0)), ip, ic, W2);
           if (multi) {
@@ -693,9 +700,17 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         };
         f2 q_ta, q01;  // (translation, alignment) and (limit 0, limit 1) quotients
         float q2;
-        if constexpr (DPP) {
+        if constexpr (ISO) {
+          E = axpy(-viol_of(0, f.ang0), f.Xp, E);
+          if (multi) {
+            E = axpy(-viol_of(1, f.ang1), f.ax1, E);
+            E = axpy(-viol_of(2, f.ang2), f.Zc, E);
+          }
+          q_ta = mk2(div_(c2, den), 0.0f);
+        } else if constexpr (DPP) {
           // no exchange latency to hide here: all divisions run as interleaved independent chains (a dependent
           // packed FMA costs a wait state, which the compiler fills with s_nop when nothing else is at hand)
+          ca = ang_prepare<ISO>(e, ip, ic, W2);
           limits_prepare();
           if (multi) {
             div2x2_(mk2(c2, ca.num), mk2(den, ca.den), mk2(c0.num, c1.num), mk2(c0.den, c1.den), q_ta, q01);
@@ -706,6 +721,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
             q2 = 0.0f;
           }
         } else {
+          ca = ang_prepare<ISO>(e, ip, ic, W2);
           q_ta = div2_(mk2(c2, ca.num), mk2(den, ca.den));
         }
         float g = q_ta.x * js_pos;
@@ -743,21 +759,25 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           }
           shfl_issue();
         }
-        ang_apply(ca, q_ta.y, js_ang, dth2);
-        if constexpr (!DPP) {  // (the shuffled kernels keep this work behind the translational exchange)
-          limits_prepare();
-          if (multi) {
-            q01 = div2_(mk2(c0.num, c1.num), mk2(c0.den, c1.den));
-            q2 = div_(c2_.num, c2_.den);
-          } else {
-            q01 = mk2(div_(c0.num, c0.den), 0.0f);
-            q2 = 0.0f;
+        if constexpr (ISO) {
+          dth2 = axpy2(kang2, bcast3(E), dth2);
+        } else {
+          ang_apply(ca, q_ta.y, js_ang, dth2);
+          if constexpr (!DPP) {  // (the shuffled kernels keep this work behind the translational exchange)
+            limits_prepare();
+            if (multi) {
+              q01 = div2_(mk2(c0.num, c1.num), mk2(c0.den, c1.den));
+              q2 = div_(c2_.num, c2_.den);
+            } else {
+              q01 = mk2(div_(c0.num, c0.den), 0.0f);
+              q2 = 0.0f;
+            }
           }
-        }
-        ang_apply(c0, q01.x, js_ang, dth2);
-        if (multi) {
-          ang_apply(c1, q01.y, js_ang, dth2);
-          ang_apply(c2_, q2, js_ang, dth2);
+          ang_apply(c0, q01.x, js_ang, dth2);
+          if (multi) {
+            ang_apply(c1, q01.y, js_ang, dth2);
+            ang_apply(c2_, q2, js_ang, dth2);
+          }
         }
         dc_th = hi3(dth2); dp_th = lo3(dth2);
       }

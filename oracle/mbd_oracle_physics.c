@@ -314,15 +314,32 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
       sp_cross3(A, B, cr);
       sp_scale3(cr, sc, e);
     }
-    ang_correct(e, ip, ic, R(m->joint_scale_ang), dp_th[l], dc_th[l]);
-    /* joint limits on the Euler angles */
-    for (int k = 0; k < 3; ++k) {
-      real a = f.ang[k], lo = R(m->rot_lo[l][k]), hi = R(m->rot_hi[l][k]);
-      real viol = a < lo ? a - lo : (a > hi ? a - hi : R(0));
-      if (k >= nr) viol = R(0);
-      real el[3];
-      sp_scale3(f.ax[k], -viol, el);
-      ang_correct(el, ip, ic, R(m->joint_scale_ang), dp_th[l], dc_th[l]);
+    if (m->iso_inertia) {
+      /* isotropic inverse inertia ib*Id: lambda = |e|/(ib_p + ib_c) and the child's share I_c^-1 n lambda is
+       * e * ib_c/(ib_p + ib_c) — linear in e, so alignment and limit errors are summed first and applied once */
+      real E[3];
+      sp_copy3(e, E);
+      for (int k = 0; k < 3; ++k) {
+        real a = f.ang[k], lo = R(m->rot_lo[l][k]), hi = R(m->rot_hi[l][k]);
+        real viol = a < lo ? a - lo : (a > hi ? a - hi : R(0));
+        if (k >= nr) viol = R(0);
+        sp_axpy3(-viol, f.ax[k], E);
+      }
+      const real ibp = ip->world ? R(0) : ip->ib[0], ibc = ic->ib[0];
+      const real kc = (ibc / (ibp + ibc)) * R(m->joint_scale_ang), kp = (ibp / (ibp + ibc)) * R(m->joint_scale_ang);
+      sp_axpy3(kc, E, dc_th[l]);
+      sp_axpy3(-kp, E, dp_th[l]);
+    } else {
+      ang_correct(e, ip, ic, R(m->joint_scale_ang), dp_th[l], dc_th[l]);
+      /* joint limits on the Euler angles */
+      for (int k = 0; k < 3; ++k) {
+        real a = f.ang[k], lo = R(m->rot_lo[l][k]), hi = R(m->rot_hi[l][k]);
+        real viol = a < lo ? a - lo : (a > hi ? a - hi : R(0));
+        if (k >= nr) viol = R(0);
+        real el[3];
+        sp_scale3(f.ax[k], -viol, el);
+        ang_correct(el, ip, ic, R(m->joint_scale_ang), dp_th[l], dc_th[l]);
+      }
     }
   }
   for (int l = 0; l < L; ++l) {

@@ -471,3 +471,19 @@ def test_metric_config_full_size_step_bitexact(gpu):
     orc_mod.build()
     _one_step(gpu, orc_mod.Oracle("f32_omp"), "humanoidrun", 1024, 50, 100, 0.1, 1, False, i=99)
     _one_step(gpu, orc_mod.Oracle("f32_omp"), "humanoidrun", 1024, 50, 100, 0.1, 1, False, i=3)
+
+
+@pytest.mark.parametrize("env_name,kw", [("humanoidrun", dict(Nsample=1024, Ndiffuse=100, disable_recommended_params=True)),
+                                         ("humanoidrun", {}),  # the reference's recommended N=8192, Ndiffuse=300
+                                         ("humanoidstandup", {}), ("ant", {}), ("hopper", {})])
+def test_long_plans_stay_finite(gpu, env_name, kw):
+    """Whole plans at the reference's own sizes: thousands of candidates visit states the short parity cases never
+    do (gimbal-singular joint frames, hard impacts).  One non-finite reward poisons the softmax of its diffusion
+    step and every mean after it, so every per-step mean reward must be finite and the plan must improve.
+    (Regression: arithmetic masking of unused Euler-angle slots once turned an overflowing angle into 0*inf.)"""
+    from mbd_hip.planners.mbd_planner import Args, run_diffusion
+    a = Args(seed=0, env_name=env_name, not_render=True, **kw)
+    rew, det = run_diffusion(a, return_details=True)
+    assert np.isfinite(det["rew_means"]).all(), int(np.where(~np.isfinite(det["rew_means"]))[0][0])
+    assert np.isfinite(det["mu_0ts"]).all() and np.isfinite(rew)
+    assert det["rew_means"][-1] > det["rew_means"][0]
