@@ -21,6 +21,14 @@ def orc():
 
 
 @pytest.fixture(scope="session")
+def orc_omp():
+    """The same float32 oracle with its rollout loop spread over the host cores (for the large parity cases)."""
+    from oracle import oracle
+    oracle.build()
+    return oracle.Oracle("f32_omp")
+
+
+@pytest.fixture(scope="session")
 def orc64():
     from oracle import oracle
     oracle.build()

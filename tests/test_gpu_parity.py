@@ -473,9 +473,30 @@ def test_metric_config_full_size_step_bitexact(gpu):
     _one_step(gpu, orc_mod.Oracle("f32_omp"), "humanoidrun", 1024, 50, 100, 0.1, 1, False, i=3)
 
 
+@pytest.mark.parametrize("name,B,sigma", [("humanoidrun", 2048, 1.0), ("humanoidrun", 2048, 0.25),
+                                          ("humanoidstandup", 1024, 1.0), ("ant", 1024, 1.0),
+                                          ("halfcheetah", 1024, 1.0), ("hopper", 1024, 1.0)])
+def test_rollout_bitexact_many_violent_candidates(gpu, orc_omp, name, B, sigma):
+    """Thousands of candidates with saturating random actions (sigma 1 clipped to +-1): falls, hard impacts,
+    joints driven into their limits and frames near the gimbal singularity — states the small cases never visit.
+    The oracle runs them on all host cores; rewards must agree bit for bit (NaN == NaN if both ever produce one)."""
+    from mbd_hip.envs import get_env
+    env = get_env(name)
+    st = env.reset(gpu.prng_key(11))
+    rng = np.random.default_rng(B + int(sigma * 100))
+    us = np.clip(rng.normal(size=(B, 50, env.action_size)) * sigma, -1.0, 1.0).astype(np.float32)
+    got = env.rollout(st, us)
+    got = (got[0] if isinstance(got, tuple) else got).cpu().numpy()
+    ref = _oenv(orc_omp, env).rollout(np.asarray(st.pipeline_state, np.float32), us)
+    ref = ref[0] if isinstance(ref, tuple) else ref
+    assert np.array_equal(got, ref, equal_nan=True), f"{name}: {np.sum(got != ref)} of {got.size} rewards differ"
+    assert np.isfinite(got).all(), f"{name}: {np.sum(~np.isfinite(got))} non-finite rewards"
+
+
 @pytest.mark.parametrize("env_name,kw", [("humanoidrun", dict(Nsample=1024, Ndiffuse=100, disable_recommended_params=True)),
                                          ("humanoidrun", {}),  # the reference's recommended N=8192, Ndiffuse=300
-                                         ("humanoidstandup", {}), ("ant", {}), ("hopper", {})])
+                                         ("humanoidstandup", {}), ("ant", {}), ("hopper", {}), ("walker2d", {}),
+                                         ("halfcheetah", {}), ("cartpole", {}), ("humanoidtrack", dict(enable_demo=True))])
 def test_long_plans_stay_finite(gpu, env_name, kw):
     """Whole plans at the reference's own sizes: thousands of candidates visit states the short parity cases never
     do (gimbal-singular joint frames, hard impacts).  One non-finite reward poisons the softmax of its diffusion
