@@ -239,7 +239,7 @@ __device__ __forceinline__ JointFrames joint_frames(const JointConst& jc, v3 Pp,
   auto opq = [](float x) { asm("" : "+v"(x)); return x; };
   float sb = fclip(opq(dot(C.Z, A.X)), -1.0f, 1.0f);
   float cb2 = ffma(-sb, sb, 1.0f);
-  float cb = sqrt_flush(cb2);
+  float cb = sqrt_floor(cb2);
   float inv = div_(1.0f, cb + 1e-10f);
   if (multi) {
     const f2 a02 = angle_unit2(mk2(-opq(dot(C.Z, A.Y)) * inv, -opq(dot(C.Y, A.X)) * inv),
@@ -706,7 +706,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
             E = axpy(-viol_of(1, f.ang1), f.ax1, E);
             E = axpy(-viol_of(2, f.ang2), f.Zc, E);
           }
-          q_ta = mk2(div_(c2, den), 0.0f);
+          q_ta = mk2(div_pos_(c2, den), 0.0f);
         } else if constexpr (DPP) {
           // no exchange latency to hide here: all divisions run as interleaved independent chains (a dependent
           // packed FMA costs a wait state, which the compiler fills with s_nop when nothing else is at hand)
@@ -714,15 +714,15 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           limits_prepare();
           if (multi) {
             div2x2_(mk2(c2, ca.num), mk2(den, ca.den), mk2(c0.num, c1.num), mk2(c0.den, c1.den), q_ta, q01);
-            q2 = div_(c2_.num, c2_.den);
+            q2 = div_pos_(c2_.num, c2_.den);
           } else {
-            q_ta = div2_(mk2(c2, ca.num), mk2(den, ca.den));
-            q01 = mk2(div_(c0.num, c0.den), 0.0f);
+            q_ta = div2_pos_(mk2(c2, ca.num), mk2(den, ca.den));
+            q01 = mk2(div_pos_(c0.num, c0.den), 0.0f);
             q2 = 0.0f;
           }
         } else {
           ca = ang_prepare<ISO>(e, ip, ic, W2);
-          q_ta = div2_(mk2(c2, ca.num), mk2(den, ca.den));
+          q_ta = div2_pos_(mk2(c2, ca.num), mk2(den, ca.den));
         }
         float g = q_ta.x * js_pos;
         const v3x2 P2 = bcast3(scale(d, g));
@@ -743,7 +743,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
             const v3x2 lcr = cross2(arm, dl2);
             const f2 lw = dot2(lcr, iinv2<ISO>(ip, ic, W2, lcr));
             float dens = ffma(invm_sum, l2, lw.x + lw.y);
-            float gs = div_(l2, dens + 1e-20f) * js_pos;
+            float gs = div_pos_(l2, dens + 1e-20f) * js_pos;
             const v3x2 Ps2 = bcast3(scale(dl, gs));
             lin2 = add2(lin2, scale2(Ps2, mk2(-ip.inv_mass, ic.inv_mass)));
             dth2 = add2(dth2, scale2(iinv2<ISO>(ip, ic, W2, cross2(arm, Ps2)), mk2(-1.0f, 1.0f)));
@@ -766,10 +766,10 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           if constexpr (!DPP) {  // (the shuffled kernels keep this work behind the translational exchange)
             limits_prepare();
             if (multi) {
-              q01 = div2_(mk2(c0.num, c1.num), mk2(c0.den, c1.den));
-              q2 = div_(c2_.num, c2_.den);
+              q01 = div2_pos_(mk2(c0.num, c1.num), mk2(c0.den, c1.den));
+              q2 = div_pos_(c2_.num, c2_.den);
             } else {
-              q01 = mk2(div_(c0.num, c0.den), 0.0f);
+              q01 = mk2(div_pos_(c0.num, c0.den), 0.0f);
               q2 = 0.0f;
             }
           }
@@ -835,7 +835,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           v3 cnt = cross_bz0(rc, dx);
           v3 icnt = iinv<ISO>(ic, Wc, cnt);
           float dent = ffma(ic.inv_mass, ct2, dot(cnt, icnt));
-          const f2 q_ng = div2_(mk2(pen, ct2), mk2(wn, dent + 1e-20f));
+          const f2 q_ng = div2_pos_(mk2(pen, ct2), mk2(wn, dent + 1e-20f));
           float dlam = q_ng.x * coll_scale;
           float gt = q_ng.y;
           v3 Pimp = mk3(0.0f, 0.0f, dlam);
@@ -877,7 +877,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         if (elast != 0.0f) vn_prev = add(v_old, cross(w_old, rc)).z;
         float vn = vpt.z;
         v3 vt = mk3(vpt.x, vpt.y, 0.0f);
-        float vtn = sqrt_flush(ffma(vt.x, vt.x, vt.y * vt.y));
+        float vtn = sqrt_floor(ffma(vt.x, vt.x, vt.y * vt.y));
         float inv = div_(1.0f, vtn + 1e-10f);
         v3 dir = mk3(vt.x * inv, vt.y * inv, 0.0f);
         v3 cn = crossz(rc), cdv = cross_bz0(rc, dir);
@@ -887,7 +887,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         float dvn = fmin_(rest, 0.0f) - vn;
         float jt_max = (mu * con_dlam[j]) * inv_dt;
         float dvt = fmin_(jt_max * wt, vtn);
-        const f2 q_nt = div2_(mk2(dvn, dvt), mk2(wn, wt));
+        const f2 q_nt = div2_sp_(mk2(dvn, dvt), mk2(wn, wt));
         float jn = q_nt.x, jt = -q_nt.y;
         v3 Pimp = mk3(dir.x * jt, dir.y * jt, jn);
         v3 nv = axpy(ic.inv_mass, Pimp, v);

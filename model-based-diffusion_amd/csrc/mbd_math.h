@@ -206,6 +206,34 @@ __device__ __forceinline__ float div_(float n, float d) {
   e = ffma(-d, q, n);
   return ffma(e, r, q);
 }
+// numerators that are non-negative by construction: clamped from below at 1e-28 (one v_max) instead of flushed
+// (a compare + a select: three issue slots for a lone wave)
+__device__ __forceinline__ float div_core_(float n, float d) {
+  float r = __builtin_amdgcn_rcpf(d);
+  float e = ffma(-d, r, 1.0f);
+  r = ffma(e, r, r);
+  float q = n * r;
+  e = ffma(-d, q, n);
+  q = ffma(e, r, q);
+  e = ffma(-d, q, n);
+  return ffma(e, r, q);
+}
+__device__ __forceinline__ f2 div2_core_(f2 n, f2 d) {
+  f2 r = mk2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
+  f2 e = fma2(-d, r, mk2(1.0f, 1.0f));
+  r = fma2(e, r, r);
+  f2 q = n * r;
+  e = fma2(-d, q, n);
+  q = fma2(e, r, q);
+  e = fma2(-d, q, n);
+  return fma2(e, r, q);
+}
+__device__ __forceinline__ float div_pos_(float n, float d) { return div_core_(fmax_(n, 1e-28f), d); }
+__device__ __forceinline__ f2 div2_pos_(f2 n, f2 d) { return div2_core_(mk2(fmax_(n.x, 1e-28f), fmax_(n.y, 1e-28f)), d); }
+// (signed numerator in the low half, non-negative one in the high half)
+__device__ __forceinline__ f2 div2_sp_(f2 n, f2 d) {
+  return div2_core_(mk2(fabs_(n.x) < 1e-28f ? 0.0f : n.x, fmax_(n.y, 1e-28f)), d);
+}
 __device__ __forceinline__ f2 div2_(f2 n, f2 d) {
   n = mk2(fabs_(n.x) < 1e-28f ? 0.0f : n.x, fabs_(n.y) < 1e-28f ? 0.0f : n.y);
   f2 r = mk2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
@@ -219,24 +247,24 @@ __device__ __forceinline__ f2 div2_(f2 n, f2 d) {
 }
 
 // ---- the solver's square root -----------------------------------------------------------------------------
-// arguments below 1e-30 give 0; above, reciprocal square root + FMA refinement, bit-identical to the correctly
-// rounded sqrtf on every float32 in [1e-30, FLT_MAX] (exhaustive: tools/probes/probe_sqrt.hip).  10 VALU instead
-// of the 16 of the compiler's expansion, which also scales denormal inputs.
-__device__ __forceinline__ float sqrt_flush(float x) {
+// the argument is clamped from below at 1e-30 (one v_max); then reciprocal square root + FMA refinement,
+// bit-identical to the correctly rounded sqrtf on every float32 in [1e-30, FLT_MAX] (exhaustive:
+// tools/probes/probe_sqrt.hip).  9 VALU instead of the 16 of the compiler's expansion, which also scales denormals.
+__device__ __forceinline__ float sqrt_floor(float x) {
+  x = fmax_(x, 1e-30f);
   float r = __builtin_amdgcn_rsqf(x);
   float g = x * r, h = 0.5f * r;
   float e = ffma(-h, g, 0.5f);
   g = ffma(g, e, g);
   h = ffma(h, e, h);
   float d = ffma(-g, g, x);
-  float s = ffma(d, h, g);
-  return x < 1e-30f ? 0.0f : s;
+  return ffma(d, h, g);
 }
 
 // two packed divisions as interleaved chains (same arithmetic as two div2_ calls)
 __device__ __forceinline__ void div2x2_(f2 na, f2 da, f2 nb, f2 db, f2& qa_out, f2& qb_out) {
-  na = mk2(fabs_(na.x) < 1e-28f ? 0.0f : na.x, fabs_(na.y) < 1e-28f ? 0.0f : na.y);
-  nb = mk2(fabs_(nb.x) < 1e-28f ? 0.0f : nb.x, fabs_(nb.y) < 1e-28f ? 0.0f : nb.y);
+  na = mk2(fmax_(na.x, 1e-28f), fmax_(na.y, 1e-28f));  // (all four are squared lengths)
+  nb = mk2(fmax_(nb.x, 1e-28f), fmax_(nb.y, 1e-28f));
   f2 ra = mk2(__builtin_amdgcn_rcpf(da.x), __builtin_amdgcn_rcpf(da.y));
   f2 rb = mk2(__builtin_amdgcn_rcpf(db.x), __builtin_amdgcn_rcpf(db.y));
   const f2 one = mk2(1.0f, 1.0f);

@@ -107,7 +107,7 @@ static void joint_frames(const mbd_model_t* m, int l, const xf_t* P, const xf_t*
    * reciprocal normalises them and the line of nodes Zc x Xp */
   real sb = sp_clip(sp_dot3(f->Zc, f->Xp), R(-1), R(1));
   real cb2 = sp_fma(-sb, sb, R(1));
-  real cb = sp_sqrt_flush(cb2);
+  real cb = sp_sqrt_floor(cb2);
   real inv = sp_div(R(1), cb + R(1e-10));
   f->ang[0] = sp_angle_unit(-sp_dot3(f->Zc, f->Yp) * inv, sp_dot3(f->Zc, f->Zp) * inv);
   f->ang[1] = sp_angle_unit(sb, cb);
@@ -129,7 +129,7 @@ static void ang_correct(const real e[3], const inert_t* ip, const inert_t* ic, r
   iinv_apply(ip, e, inp);
   iinv_apply(ic, e, inc);
   real den = sp_dot3(e, inp) + sp_dot3(e, inc);
-  real g = sp_div(sp_dot3(e, e), den + R(1e-20)) * scale;
+  real g = sp_div_pos(sp_dot3(e, e), den + R(1e-20)) * scale;
   sp_axpy3(g, inc, dth_c);
   sp_axpy3(-g, inp, dth_p);
 }
@@ -267,7 +267,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_cross3(rp, d, cp); sp_cross3(rc, d, cc);
     iinv_apply(ip, cp, icp); iinv_apply(ic, cc, icc);
     real den = sp_fma(ip->inv_mass + ic->inv_mass, c2, sp_dot3(cp, icp) + sp_dot3(cc, icc));
-    real g = sp_div(c2, den + R(1e-20)) * R(m->joint_scale_pos);
+    real g = sp_div_pos(c2, den + R(1e-20)) * R(m->joint_scale_pos);
     real Pimp[3], mom[3], t[3];
     sp_scale3(d, g, Pimp);
     sp_scale3(Pimp, ic->inv_mass, dc_p[l]);
@@ -290,7 +290,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
       sp_cross3(rp, dl, lp); sp_cross3(rc, dl, lc);
       iinv_apply(ip, lp, ilp); iinv_apply(ic, lc, ilc);
       real dens = sp_fma(ip->inv_mass + ic->inv_mass, l2, sp_dot3(lp, ilp) + sp_dot3(lc, ilc));
-      real gs = sp_div(l2, dens + R(1e-20)) * R(m->joint_scale_pos);
+      real gs = sp_div_pos(l2, dens + R(1e-20)) * R(m->joint_scale_pos);
       real Ps[3], u[3];
       sp_scale3(dl, gs, Ps);
       sp_scale3(Ps, ic->inv_mass, u); sp_add3(dc_p[l], u, dc_p[l]);
@@ -372,7 +372,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_sub3(con[k].pos, x[l].p, rc);
     crossz(rc, cn); iinv_apply_z0(&in[l], cn, icn);
     real w = in[l].inv_mass + dot_az0(cn, icn);
-    real dlam = sp_div(pen, w) * R(m->collide_scale);
+    real dlam = sp_div_pos(pen, w) * R(m->collide_scale);
     con[k].dlam = dlam;
     real Pimp[3] = {0, 0, dlam}, mom[3];
     /* static friction: undo the tangential motion of the contact point over this substep if the
@@ -387,7 +387,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     real cnt[3], icnt[3];
     cross_bz0(rc, dx, cnt); iinv_apply(&in[l], cnt, icnt);
     real dent = sp_fma(in[l].inv_mass, ct2, sp_dot3(cnt, icnt));
-    real gt = sp_div(ct2, dent + R(1e-20));
+    real gt = sp_div_pos(ct2, dent + R(1e-20));
     real lim = mu * dlam;
     if ((ct2 * gt) * gt < lim * lim) { Pimp[0] = (-gt) * dx[0]; Pimp[1] = (-gt) * dx[1]; }
     sp_axpy3(in[l].inv_mass, Pimp, cd_p[l]);
@@ -418,7 +418,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_cross3(xd_prev[l].w, rc, t); sp_add3(xd_prev[l].v, t, vprev);
     real vn = vpt[2], vn_prev = vprev[2];
     real vt[3] = {vpt[0], vpt[1], R(0)};
-    real vtn = sp_sqrt_flush(sp_fma(vt[0], vt[0], vt[1] * vt[1]));
+    real vtn = sp_sqrt_floor(sp_fma(vt[0], vt[0], vt[1] * vt[1]));
     real inv = sp_div(R(1), vtn + R(1e-10));
     real dir[3], cn[3], icn[3], cdv[3], icd[3];
     sp_set3(dir, vt[0] * inv, vt[1] * inv, R(0));
@@ -429,7 +429,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     real dvn = sp_min(rest, R(0)) - vn;
     real jt_max = (mu * con[k].dlam) * inv_dt; /* friction impulse bound mu * lambda_n / h */
     real dvt = sp_min(jt_max * wt, vtn);
-    real jn = sp_div(dvn, wn), jt = -sp_div(dvt, wt);
+    real jn = sp_div(dvn, wn), jt = -sp_div_pos(dvt, wt);
     real Pimp[3] = {dir[0] * jt, dir[1] * jt, jn};
     sp_axpy3(in[l].inv_mass, Pimp, xd[l].v);
     real mom[3];

@@ -32,11 +32,12 @@ static inline real sp_fma(real a, real b, real c) {
 static inline real sp_sqrt(real x) {
   return sizeof(real) == 4 ? (real)__builtin_sqrtf((float)x) : (real)__builtin_sqrt((double)x);
 }
-/* the solver's square root (cos of the middle Euler angle, tangential contact speed): arguments below 1e-30
- * give 0, everything else is the correctly rounded root.  (The flush lets the kernels use the 8-instruction
- * rsq + FMA sequence, which tools/probes/probe_sqrt.hip shows bit-identical to sqrtf on EVERY float32 in
- * [1e-30, FLT_MAX], instead of the 16-instruction expansion that also covers denormal inputs.) */
-static inline real sp_sqrt_flush(real x) { return x < R(1e-30) ? R(0) : sp_sqrt(x); }
+/* the solver's square root (cos of the middle Euler angle, tangential contact speed): the argument is clamped from
+ * below at 1e-30 (result >= 1e-15), everything else is the correctly rounded root.  (The clamp lets the kernels
+ * use the 8-instruction rsq + FMA sequence, which tools/probes/probe_sqrt.hip shows bit-identical to sqrtf on EVERY
+ * float32 in [1e-30, FLT_MAX], instead of the 16-instruction expansion that also covers denormal inputs; a clamp
+ * rather than a flush because one v_max is cheaper than a compare and a select.) */
+static inline real sp_sqrt_floor(real x) { return sp_sqrt(x < R(1e-30) ? R(1e-30) : x); }
 static inline real sp_abs(real x) { return sizeof(real) == 4 ? (real)__builtin_fabsf((float)x) : (real)__builtin_fabs((double)x); }
 static inline real sp_min(real a, real b) { return a < b ? a : b; }
 static inline real sp_max(real a, real b) { return a > b ? a : b; }
@@ -46,6 +47,11 @@ static inline real sp_clip(real v, real lo, real hi) { return v < lo ? lo : (v >
  * every quotient and residual a normal number, which is what lets the GPU use the bare reciprocal/FMA
  * refinement sequence and still round exactly like this IEEE division — tools/probes/probe_div.hip) */
 static inline real sp_div(real n, real d) { return (sp_abs(n) < R(1e-28) ? R(0) : n) / d; }
+/* the same for numerators that are non-negative by construction (squared lengths, penetration depths, speed
+ * magnitudes): clamped from below at 1e-28 instead of flushed — one max instead of a compare and a select, which
+ * costs the kernels three issue slots (a VALU compare alone holds the lone wave's issue port for two).  The
+ * quotient of such a floor value is at most 1e-8 and always multiplies something that vanishes with the numerator. */
+static inline real sp_div_pos(real n, real d) { return (n < R(1e-28) ? R(1e-28) : n) / d; }
 
 /* ---- vectors ------------------------------------------------------------------------------------- */
 /* dot = fma(a0,b0, fma(a1,b1, a2*b2)) */
