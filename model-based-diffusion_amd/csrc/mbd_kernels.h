@@ -818,16 +818,20 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         v3 cd_p = mk3(0, 0, 0), cd_th = mk3(0, 0, 0);
 #pragma unroll
         for (int j = 0; j < MAXCOL; ++j) {
-          v3 ctr = add(p, rot(col_pos[j], r));
+          const v3 off = rot(col_pos[j], r);
+          v3 ctr = add(p, off);
           float pen = col_rad[j] - ctr.z;
           bool active = col_has[j] && pen > 0.0f;
-          v3 pos = mk3(ctr.x, ctr.y, ctr.z - ffma(-0.5f, pen, col_rad[j]));
-          v3 rc = sub(pos, p);
+          // the contact point sits h below the sphere's centre: lever arm = rotated offset minus that drop,
+          // link-frame coordinates = collider offset plus the drop rotated back
+          const float h = ffma(-0.5f, pen, col_rad[j]);
+          v3 pos = mk3(ctr.x, ctr.y, ctr.z - h);
+          v3 rc = mk3(off.x, off.y, off.z - h);
           v3 cn = crossz(rc);
           v3 icn = iinv_z0<ISO>(ic, Wc, cn);
           float wn = ic.inv_mass + dot_az0(cn, icn);
           // (dlam and gt share one packed division below)
-          v3 rl = irot(rc, r);
+          v3 rl = add(col_pos[j], irot_z(-h, r));
           v3 pprev = add(p_prev, rot(rl, r_prev));
           v3 dx = sub(pos, pprev);
           dx.z = 0.0f;

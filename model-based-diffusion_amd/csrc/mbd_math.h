@@ -72,6 +72,13 @@ MBD_HD v3 rot(v3 v, q4 q) {
 MBD_HD q4 sel4(bool c, q4 a, q4 b) { return q4{c ? a.w : b.w, c ? a.x : b.x, c ? a.y : b.y, c ? a.z : b.z}; }
 MBD_HD q4 conj(q4 q) { return q4{q.w, -q.x, -q.y, -q.z}; }
 MBD_HD v3 irot(v3 v, q4 q) { return rot(v, conj(q)); }
+// R(q)^T (0,0,d): inverse rotation of a vector along z, written out (about half of the general irot)
+MBD_HD v3 irot_z(float d, q4 q) {
+  float a = q.y * d, b = q.x * d;
+  float tx = -(a + a), ty = b + b;
+  float cx = q.z * ty, cy = -(q.z * tx), cz = ffma(-q.x, ty, q.y * tx);
+  return v3{ffma(q.w, tx, cx), ffma(q.w, ty, cy), d + cz};
+}
 MBD_HD q4 qmul(q4 a, q4 b) {
   q4 o;
   o.w = ffma(-a.z, b.z, ffma(-a.y, b.y, ffma(-a.x, b.x, a.w * b.w)));

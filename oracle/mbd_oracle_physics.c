@@ -367,9 +367,11 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     con[k].active = pen > R(0);
     con[k].dlam = 0;
     if (!con[k].active) continue;
-    sp_set3(con[k].pos, ctr[0], ctr[1], ctr[2] - sp_fma(R(-0.5), pen, rad));
-    real rc[3], cn[3], icn[3];
-    sp_sub3(con[k].pos, x[l].p, rc);
+    /* the contact point sits h below the sphere's centre; its lever arm is the rotated collider offset minus that
+     * drop (not pos - p), its link-frame coordinates are the collider offset plus the drop rotated back */
+    const real h = sp_fma(R(-0.5), pen, rad);
+    sp_set3(con[k].pos, ctr[0], ctr[1], ctr[2] - h);
+    real rc[3] = {t[0], t[1], t[2] - h}, cn[3], icn[3];
     crossz(rc, cn); iinv_apply_z0(&in[l], cn, icn);
     real w = in[l].inv_mass + dot_az0(cn, icn);
     real dlam = sp_div_pos(pen, w) * R(m->collide_scale);
@@ -380,7 +382,8 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
      * lambda_t t = -dx_t * |dx_t|^2 / (|dx_t|^2/m + (rc x dx_t).I^-1 (rc x dx_t)); the cone test
      * |lambda_t| < mu lambda_n is done on squares — one division, no square root */
     real rl[3], pprev[3], dx[3];
-    sp_irot(rc, x[l].r, rl); sp_rot(rl, x_prev[l].r, t); sp_add3(x_prev[l].p, t, pprev);
+    sp_irot_z(-h, x[l].r, rl); sp_add3(cl, rl, rl);
+    sp_rot(rl, x_prev[l].r, t); sp_add3(x_prev[l].p, t, pprev);
     sp_sub3(con[k].pos, pprev, dx);
     dx[2] = R(0);
     real ct2 = sp_fma(dx[0], dx[0], dx[1] * dx[1]);

@@ -91,6 +91,15 @@ static inline void sp_irot(const real v[3], const real q[4], real o[3]) {
   real qc[4] = {q[0], -q[1], -q[2], -q[3]};
   sp_rot(v, qc, o);
 }
+/* R(q)^T (0,0,d): the inverse rotation of a vector along z (the drop from a sphere's centre to its contact point),
+ * written out — roughly half the operations of the general sp_irot */
+static inline void sp_irot_z(real d, const real q[4], real o[3]) {
+  real a = q[2] * d, b = q[1] * d;
+  real tx = -(a + a), ty = b + b;
+  real cx = q[3] * ty, cy = -(q[3] * tx), cz = sp_fma(-q[1], ty, q[2] * tx);
+  real x = sp_fma(q[0], tx, cx), y = sp_fma(q[0], ty, cy), z = d + cz;
+  o[0] = x; o[1] = y; o[2] = z;
+}
 static inline void sp_qmul(const real a[4], const real b[4], real o[4]) {
   real w = sp_fma(-a[3], b[3], sp_fma(-a[2], b[2], sp_fma(-a[1], b[1], a[0] * b[0])));
   real x = sp_fma(-a[3], b[2], sp_fma(a[2], b[3], sp_fma(a[1], b[0], a[0] * b[1])));
