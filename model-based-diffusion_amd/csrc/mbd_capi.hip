@@ -197,12 +197,12 @@ int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B
   // of one CU, which single-wave workgroups do not achieve once a launch (or several concurrent plans) puts four
   // waves on a CU — N=4096: 1.29 ms with one wave per workgroup, 0.75 ms with four; N=1024: 0.720 -> 0.710 ms
   // (tools/gpu_wpb.sh).  MBD_WPB overrides for experiments.
-  int wpb = 4;
-  if (const char* w = std::getenv("MBD_WPB")) wpb = std::atoi(w) == 4 ? 4 : (std::atoi(w) == 2 ? 2 : 1);
+  static const int wpb_env = [] { const char* w = std::getenv("MBD_WPB"); return w ? std::atoi(w) : 0; }();
+  static const long lds_env = [] { const char* r = std::getenv("MBD_LDS_RESERVE"); return r ? std::atol(r) : -1L; }();
+  const int wpb = wpb_env == 1 || wpb_env == 2 ? wpb_env : 4;
   dim3 grid((waves + wpb - 1) / wpb), block(64 * wpb);
   // up to one workgroup per CU: keep the CU to that workgroup (see launch_rollout_kernel); above, CUs are shared
-  size_t lds = (wpb == 4 && grid.x <= 256) ? 96 * 1024 : 0;
-  if (const char* r = std::getenv("MBD_LDS_RESERVE")) lds = (size_t)std::atoi(r);
+  const size_t lds = lds_env >= 0 ? (size_t)lds_env : ((wpb == 4 && grid.x <= 256) ? 96 * 1024 : 0);
 #define MBD_LAUNCH(...) \
   launch_rollout_kernel(rollout_kernel<__VA_ARGS__>, env->device, grid, block, lds, stream, P)
   const bool humanoid_shape = env->lps == 16 && iso && !env->slides && env->max_children <= 3;
