@@ -15,6 +15,7 @@ rewards per step.  `value` is the whole-job rate in units of 1024-candidate diff
 Inputs are resident in HBM when the timed region starts; data is synthetic (seeded PRNG).
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -213,7 +214,8 @@ def main():
         for seed in range(8):
             a = Args(seed=seed, env_name=ENV, Nsample=N_PER_GPU, Hsample=H, Ndiffuse=ND, temp_sample=TEMP,
                      disable_recommended_params=True, not_render=True)
-            rews.append(float(run_diffusion(a, device=local_rank)))
+            with contextlib.redirect_stdout(sys.stderr):  # the reference prints "init sigma = ..." (:92); stdout
+                rews.append(float(run_diffusion(a, device=local_rank)))  # carries the one JSON line only
         final = {"seeds": list(range(8)), "rew_final": rews, "mean": float(np.mean(rews)),
                  "std": float(np.std(rews))}
     plan.close()
