@@ -10,11 +10,12 @@
 //
 // Layout of the rollout kernel (the one that matters): ONE LINK PER LANE.  A candidate occupies LPS
 // consecutive lanes of a wavefront (LPS = 16 for the 11-link humanoid, 8 for the 7-link cheetah, 4 for
-// the hopper), 64/LPS candidates per wavefront, one wavefront per workgroup, so N=1024 humanoid
-// candidates are 256 single-wave workgroups = one per CU, spread evenly over the 8 XCDs.  The 13-float
-// link state, its previous pose and ~90 per-link model constants stay in VGPRs for the whole
-// H x n_frames rollout; a parent's state and the children's constraint contributions move between
-// lanes with ds_bpermute (no LDS allocation, no barriers); HBM is touched only for the action fetch
+// the hopper), 64/LPS candidates per wavefront; a workgroup is four INDEPENDENT wavefronts (that is how the
+// dispatcher puts one wavefront on each SIMD of a CU), so N=1024 humanoid candidates are 256 wavefronts on
+// 64 CUs.  The 13-float link state, its previous pose and ~90 per-link model constants stay in VGPRs for
+// the whole H x n_frames rollout; a parent's state and the children's constraint contributions move
+// between lanes by DPP row shifts when the link tree fits one of the instantiated layouts (every built-in
+// model), by ds_bpermute otherwise (no LDS data, no barriers); HBM is touched only for the action fetch
 // (prefetched one control step ahead) and the reward store.  All arithmetic follows mbd_math.h.
 #pragma once
 
@@ -1246,7 +1247,7 @@ __global__ __launch_bounds__(kWmE * kWmG) void wmean_kernel(const float* __restr
 }
 
 // ---- path-integral baselines (mbd/planners/path_integral.py:39-52) ---------------------------------------
-// cma-es: s[e] = sqrt(sum_n w_n (Y0s[n][e] - mu_t[e])^2), sequential fma over n like wmean_kernel
+// cma-es: s[e] = sqrt(sum_n w_n (Y0s[n][e] - mu_t[e])^2), one thread per output, sequential fma over n
 __global__ __launch_bounds__(64) void cma_spread_kernel(const float* __restrict__ weights,
                                                         const float* __restrict__ Y0s, int N, int HNu,
                                                         const float* __restrict__ mu_t, float* __restrict__ s_out) {
