@@ -298,6 +298,25 @@ def test_full_size_properties_humanoidrun(gpu):
     assert np.isfinite(d1["mu_0ts"]).all() and np.abs(d1["mu_0ts"]).max() <= 1.0
 
 
+@pytest.mark.parametrize("name,B", [("humanoidrun", 1024), ("hopper", 1000), ("halfcheetah", 777), ("ant", 515)])
+def test_candidates_are_independent_of_their_neighbours(gpu, name, B):
+    """Full-size property without the oracle: a candidate's rewards do not depend on where it sits in the batch —
+    permuting the batch permutes the rewards, and a prefix of the batch gives the prefix of the rewards, bit for
+    bit.  (Candidates share wavefronts — 4 to 16 per wave — and, for the small models, DPP rows: any leak
+    between lane groups, or any dependence on the tail handling of a partial last wavefront, shows up here.)"""
+    from mbd_hip.envs import get_env
+    env = get_env(name)
+    st = env.reset(gpu.prng_key(5))
+    g = np.random.default_rng(B)
+    us = np.clip(g.normal(size=(B, 50, env.action_size)) * 0.7, -1.0, 1.0).astype(np.float32)
+    base = env.rollout(st, us).cpu().numpy()
+    perm = g.permutation(B)
+    assert np.array_equal(env.rollout(st, us[perm]).cpu().numpy(), base[perm])
+    for cut in (1, 3, B // 2 + 1, B - 1):
+        assert np.array_equal(env.rollout(st, us[:cut]).cpu().numpy(), base[:cut]), cut
+    assert np.isfinite(base).all()
+
+
 @pytest.mark.parametrize("impl", [1, 0])
 def test_two_shards_on_one_gpu_match_unsharded(gpu, impl, monkeypatch):
     """The N>1 code path on a single GPU: two plans owning candidates [0,N/2) and [N/2,N) plus a manual
