@@ -582,6 +582,11 @@ extern "C" int mbd_plan_create(mbd_env* env, const mbd_plan_config* cfg, mbd_pla
     if (cfg->Hsample != 50) return fail(MBD_ERR_INVALID, "demos require Hsample == 50 (xref has 50 rows)");
   }
   if ((size_t)cfg->Nsample * sizeof(float) > 160 * 1024 - 1024) return fail(MBD_ERR_UNSUPPORTED, "Nsample too large for the LDS-resident score kernel");
+  if ((size_t)cfg->Nsample * sizeof(float) > 48 * 1024) {  // logp0 [N] in dynamic LDS: beyond the default window
+    HIP_TRY(hipSetDevice(env->device));
+    HIP_TRY(hipFuncSetAttribute((const void*)score_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+    HIP_TRY(hipFuncSetAttribute((const void*)cem_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024));
+  }
   HIP_TRY(hipSetDevice(env->device));
   std::unique_ptr<mbd_plan> guard(new mbd_plan());
   mbd_plan* p = guard.get();

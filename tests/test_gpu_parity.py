@@ -178,7 +178,7 @@ def _one_step(gpu, orc, name, N, H, Nd, temp, impl, demo, i=None):
 
 
 @pytest.mark.parametrize("name,H,demo", [("car2d", 7, False), ("car2d", 50, True), ("hopper", 11, False)])
-@pytest.mark.parametrize("N", [1, 3, 63, 64, 65, 1000, 1024, 1025, 2500, 5003])
+@pytest.mark.parametrize("N", [1, 3, 63, 64, 65, 1000, 1024, 1025, 2500, 5003, 20011])
 def test_score_update_ragged_sizes(gpu, orc, name, H, demo, N):
     """mbd_plan_score_update on its own, at candidate counts around every boundary of its two kernels (one
     1024-thread workgroup; 16-output x 64-group tiles): resident Y0s from the sampler, SYNTHETIC rewards (ties,
