@@ -116,3 +116,25 @@ def test_dpp_lane_layouts_of_the_builtin_models(lib):
         for l in range(1, L):
             slot = sum(1 for c in range(l) if parent[c] == parent[l])
             assert shifts[slot] != 0 and lane[parent[l]] == lane[l] + shifts[slot], (name, l)
+
+
+def test_c_abi_argument_errors_without_a_device(lib):
+    """Every export returns an int status and leaves a message in mbd_last_error(); NULL / out-of-range arguments
+    are rejected before anything touches a device (so this runs on a CPU-only box), destroying NULL is fine."""
+    from mbd_hip import _capi
+    lib.mbd_last_error.restype = C.c_char_p
+    INVALID = _capi.MBD_ERR_INVALID
+    assert lib.mbd_prng_split(None, 2, 1, None) == INVALID and b"prng_split" in lib.mbd_last_error()
+    assert lib.mbd_env_info(None, None, None, None, None, None, None) == INVALID
+    assert lib.mbd_device_count(None) == INVALID
+    assert lib.mbd_plan_create(None, None, None) == INVALID
+    assert lib.mbd_plan_schedule(None, None, None, None) == INVALID
+    assert lib.mbd_plan_set_state0(None, None) == INVALID
+    assert lib.mbd_plan_run(None, None, None, None, None, None) == INVALID
+    assert lib.mbd_plan_sample_rollout(None, 1, None, None, None, None, None) == INVALID
+    assert lib.mbd_plan_score_update(None, 1, None, None, None, None, None, None, None) == INVALID
+    assert lib.mbd_env_create_model(None, 0, None, None, C.c_float(0), None) == INVALID
+    assert lib.mbd_env_destroy(None) == 0 and lib.mbd_plan_destroy(None) == 0
+    n = C.c_int(-1)
+    assert lib.mbd_device_count(C.byref(n)) == 0 and n.value >= 0
+    assert lib.mbd_version() >= 1
