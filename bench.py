@@ -123,7 +123,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     __graft_entry__.build()  # serialised across ranks by a file lock; a no-op when the library is fresh
-    distributed = world > 1
+    # MBD_FORCE_DIST=1: take the multi-rank code path (RCCL init, all-gather, barrier, max-reduce) with ONE rank —
+    # what the single-GPU test box can exercise of it (tests/test_gpu_parity.py)
+    distributed = world > 1 or os.environ.get("MBD_FORCE_DIST") == "1"
     backend = os.environ.get("MBD_DIST_BACKEND", "nccl")  # "gloo": 2-rank dry runs on a single-GPU box
     n_dev = torch.cuda.device_count()
     if distributed:

@@ -527,3 +527,22 @@ def test_long_plans_stay_finite(gpu, env_name, kw):
     assert np.isfinite(det["rew_means"]).all(), int(np.where(~np.isfinite(det["rew_means"]))[0][0])
     assert np.isfinite(det["mu_0ts"]).all() and np.isfinite(rew)
     assert det["rew_means"][-1] > det["rew_means"][0]
+
+
+def test_bench_multirank_code_path_on_rccl_with_one_rank(gpu):
+    """bench.py's N>1 branch — torch.distributed `nccl` (= RCCL) initialisation with a device id, the per-step
+    all_gather_into_tensor of device buffers, the barriers and the max-over-ranks reduction — launched the way the
+    driver launches it, with the one rank this box has (MBD_FORCE_DIST=1).  It must print one JSON line whose
+    rate is in the same range as the plain single-GPU loop."""
+    import json, os, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, MBD_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
+           "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20",
+           "--warmup", "3", "--no-cpu-baseline", "--no-final-reward"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["collective"].startswith("all_gather") and d["value"] > 300.0
