@@ -534,11 +534,14 @@ def test_bench_multirank_code_path_on_rccl_with_one_rank(gpu):
     all_gather_into_tensor of device buffers, the barriers and the max-over-ranks reduction — launched the way the
     driver launches it, with the one rank this box has (MBD_FORCE_DIST=1).  It must print one JSON line whose
     rate is in the same range as the plain single-GPU loop."""
-    import json, os, subprocess, sys
+    import json, os, socket, subprocess, sys
     from conftest import ROOT
     env = dict(os.environ, MBD_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as sk:  # a free rendezvous port
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr",
-           "127.0.0.1", "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "20",
            "--warmup", "3", "--no-cpu-baseline", "--no-final-reward"]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
