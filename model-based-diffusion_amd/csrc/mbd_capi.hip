@@ -72,6 +72,7 @@ struct mbd_env {
   bool has_xref = false;
   float rew_xref = 0.0f;
   int lps = 16, max_children = 0, max_col = 0, max_rot = 0;
+  bool diag_inertia = true;  // every body-frame inverse-inertia tensor is exactly diagonal
   bool slides = false;
   bool slide_limits = false;  // any slide dof with a finite range
   // DPP layout (kernels.h "lane exchange without the LDS"): lane <-> link tables when the tree fits the shifts
@@ -223,6 +224,7 @@ int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B
     if (iso) MBD_LAUNCH(16, true, true, 4, 2); else MBD_LAUNCH(16, false, true, 4, 2);
   } else if (env->lps == 8 && env->dpp_family == 1) {  // walker2d, halfcheetah
     if (iso) MBD_LAUNCH(8, true, true, 4, 2, 1, -3, 0);
+    else if (env->diag_inertia) MBD_LAUNCH(8, false, true, 4, 2, 1, -3, 0, 0, true);  // walker2d
     else MBD_LAUNCH(8, false, true, 4, 2, 1, -3, 0);
   } else if (env->lps == 8 && env->dpp_family == 2) {
     if (iso) MBD_LAUNCH(8, true, true, 4, 2, 1, 0, 0);
@@ -231,6 +233,7 @@ int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B
     if (iso) MBD_LAUNCH(8, true, true, 4, 2); else MBD_LAUNCH(8, false, true, 4, 2);
   } else if (env->dpp_family == 2) {  // hopper, cartpole
     if (iso) MBD_LAUNCH(4, true, true, 4, 2, 1, 0, 0);
+    else if (env->diag_inertia) MBD_LAUNCH(4, false, true, 4, 2, 1, 0, 0, 0, true);  // hopper
     else MBD_LAUNCH(4, false, true, 4, 2, 1, 0, 0);
   } else {
     if (iso) MBD_LAUNCH(4, true, true, 4, 2); else MBD_LAUNCH(4, false, true, 4, 2);
@@ -429,6 +432,7 @@ extern "C" int mbd_env_create_model(const char* env_name, int device, const mbd_
     if (m.parent[l] >= 0) nch[m.parent[l]]++;
     if (m.n_slide[l] > 0 || m.n_rot[l] == 0) e->slides = true;  // slides and welds both need the generic kernels
     if (m.n_rot[l] > e->max_rot) e->max_rot = m.n_rot[l];
+    if (m.inv_inertia[l][3] != 0.0f || m.inv_inertia[l][4] != 0.0f || m.inv_inertia[l][5] != 0.0f) e->diag_inertia = false;
     for (int k = 0; k < m.n_slide[l]; ++k)
       if (m.slide_lo[l][k] > -1e8f || m.slide_hi[l][k] < 1e8f) e->slide_limits = true;
   }

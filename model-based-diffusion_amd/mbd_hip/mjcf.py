@@ -332,6 +332,9 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
         lam, V = np.linalg.eigh(I)
         lam_s = lam ** (1.0 - custom["spring_inertia_scale"])
         Iinv = V @ np.diag(1.0 / lam_s) @ V.T
+        # round-off of the eigen-decomposition is not structure: off-diagonal entries 1e-12 below the trace are
+        # exact zeros (axis-aligned capsules and boxes then have exactly diagonal tensors, which the kernels use)
+        Iinv[np.abs(Iinv) < 1e-12 * np.trace(Iinv)] = 0.0
         F["inv_mass"][l] = 1.0 / (mass ** (1.0 - custom["spring_mass_scale"]))
         F["inv_inertia"][l] = [Iinv[0, 0], Iinv[1, 1], Iinv[2, 2], Iinv[0, 1], Iinv[0, 2], Iinv[1, 2]]
         if not (np.allclose(Iinv, Iinv[0, 0] * np.eye(3), rtol=1e-6, atol=1e-9)):
