@@ -204,40 +204,48 @@ int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B
   dim3 grid((waves + wpb - 1) / wpb), block(64 * wpb);
   // up to one workgroup per CU: keep the CU to that workgroup (see launch_rollout_kernel); above, CUs are shared
   const size_t lds = lds_env >= 0 ? (size_t)lds_env : ((wpb == 4 && grid.x <= 256) ? 96 * 1024 : 0);
+// rollout_kernel<LPS, ISO, SLIDES, MAXCH, MAXCOL, D0, D1, D2, D3, DIAG, MULTI>: L(...) fixes everything but MULTI,
+// which follows the model (a joint with more than one hinge dof).  The humanoid-shaped instantiations are MULTI.
 #define MBD_LAUNCH(...) \
   launch_rollout_kernel(rollout_kernel<__VA_ARGS__>, env->device, grid, block, lds, stream, P)
-  const bool humanoid_shape = env->lps == 16 && iso && !env->slides && env->max_children <= 3;
+#define L(...)                                              \
+  do {                                                      \
+    if (multi) MBD_LAUNCH(__VA_ARGS__, true);               \
+    else MBD_LAUNCH(__VA_ARGS__, false);                    \
+  } while (0)
+  const bool multi = env->max_rot > 1, diag = env->diag_inertia;
+  const bool humanoid_shape = env->lps == 16 && iso && !env->slides && env->max_children <= 3 && multi;
   const bool dpp_h = env->dpp_family == 0;
   if (humanoid_shape && env->max_col <= 1 && dpp_h) {
-    MBD_LAUNCH(16, true, false, 3, 1, kDppD0, kDppD1, kDppD2);
+    MBD_LAUNCH(16, true, false, 3, 1, kDppD0, kDppD1, kDppD2, 0, false, true);
   } else if (humanoid_shape && env->max_col <= 5 && dpp_h) {
-    MBD_LAUNCH(16, true, false, 3, 5, kDppD0, kDppD1, kDppD2);
+    MBD_LAUNCH(16, true, false, 3, 5, kDppD0, kDppD1, kDppD2, 0, false, true);
   } else if (humanoid_shape && env->max_col <= 1) {
-    MBD_LAUNCH(16, true, false, 3, 1);  // humanoid-like trees that do not fit the DPP shifts
+    MBD_LAUNCH(16, true, false, 3, 1, 0, 0, 0, 0, false, true);  // humanoid-like trees that do not fit the DPP shifts
   } else if (humanoid_shape && env->max_col <= 5) {
-    MBD_LAUNCH(16, true, false, 3, 5);  // humanoidstandup: up to 5 sphere colliders on one link
+    MBD_LAUNCH(16, true, false, 3, 5, 0, 0, 0, 0, false, true);  // humanoidstandup: up to 5 colliders on one link
   } else if (env->lps == 16 && iso && !env->slides && env->max_col <= 2 && env->dpp_family == 3) {
-    MBD_LAUNCH(16, true, false, 4, 2, 1, -2, -4, -6);  // ant
+    L(16, true, false, 4, 2, 1, -2, -4, -6, false);  // ant
   } else if (env->lps == 16 && iso && !env->slides && env->max_col <= 2) {
-    MBD_LAUNCH(16, true, false, 4, 2);  // ant-like: free root with four legs, no slide / weld joints
+    L(16, true, false, 4, 2, 0, 0, 0, 0, false);  // ant-like: free root, no slide / weld joints
   } else if (env->lps == 16) {
-    if (iso) MBD_LAUNCH(16, true, true, 4, 2); else MBD_LAUNCH(16, false, true, 4, 2);
+    if (iso) L(16, true, true, 4, 2, 0, 0, 0, 0, false); else L(16, false, true, 4, 2, 0, 0, 0, 0, false);
   } else if (env->lps == 8 && env->dpp_family == 1) {  // walker2d, halfcheetah
-    if (iso) MBD_LAUNCH(8, true, true, 4, 2, 1, -3, 0);
-    else if (env->diag_inertia) MBD_LAUNCH(8, false, true, 4, 2, 1, -3, 0, 0, true);  // walker2d
-    else MBD_LAUNCH(8, false, true, 4, 2, 1, -3, 0);
+    if (iso) L(8, true, true, 4, 2, 1, -3, 0, 0, false);
+    else if (diag) L(8, false, true, 4, 2, 1, -3, 0, 0, true);  // walker2d
+    else L(8, false, true, 4, 2, 1, -3, 0, 0, false);
   } else if (env->lps == 8 && env->dpp_family == 2) {
-    if (iso) MBD_LAUNCH(8, true, true, 4, 2, 1, 0, 0);
-    else MBD_LAUNCH(8, false, true, 4, 2, 1, 0, 0);
+    if (iso) L(8, true, true, 4, 2, 1, 0, 0, 0, false); else L(8, false, true, 4, 2, 1, 0, 0, 0, false);
   } else if (env->lps == 8) {
-    if (iso) MBD_LAUNCH(8, true, true, 4, 2); else MBD_LAUNCH(8, false, true, 4, 2);
+    if (iso) L(8, true, true, 4, 2, 0, 0, 0, 0, false); else L(8, false, true, 4, 2, 0, 0, 0, 0, false);
   } else if (env->dpp_family == 2) {  // hopper, cartpole
-    if (iso) MBD_LAUNCH(4, true, true, 4, 2, 1, 0, 0);
-    else if (env->diag_inertia) MBD_LAUNCH(4, false, true, 4, 2, 1, 0, 0, 0, true);  // hopper
-    else MBD_LAUNCH(4, false, true, 4, 2, 1, 0, 0);
+    if (iso) L(4, true, true, 4, 2, 1, 0, 0, 0, false);
+    else if (diag) L(4, false, true, 4, 2, 1, 0, 0, 0, true);  // hopper
+    else L(4, false, true, 4, 2, 1, 0, 0, 0, false);
   } else {
-    if (iso) MBD_LAUNCH(4, true, true, 4, 2); else MBD_LAUNCH(4, false, true, 4, 2);
+    if (iso) L(4, true, true, 4, 2, 0, 0, 0, 0, false); else L(4, false, true, 4, 2, 0, 0, 0, 0, false);
   }
+#undef L
 #undef MBD_LAUNCH
   HIP_TRY(hipGetLastError());
   return MBD_OK;
@@ -443,7 +451,7 @@ extern "C" int mbd_env_create_model(const char* env_name, int device, const mbd_
   }
   if (e->max_children > kMaxChildren) { return fail(MBD_ERR_UNSUPPORTED, "a link has %d children > %d", e->max_children, kMaxChildren); }
   {
-    const bool standup_shape = e->lps == 16 && m.iso_inertia && !e->slides && e->max_children <= 3;
+    const bool standup_shape = e->lps == 16 && m.iso_inertia && !e->slides && e->max_children <= 3 && e->max_rot > 1;
     if (e->max_col > (standup_shape ? 5 : 2)) {
       const int mc = e->max_col;
       return fail(MBD_ERR_UNSUPPORTED, "a link has %d sphere colliders: more than this kernel family is built for", mc);

@@ -373,7 +373,7 @@ __device__ __forceinline__ v3 iinv_z0(const Inert<ISO>& in, const WInert<ISO>& W
 // slot).  Groups of LPS lanes never straddle a 16-lane DPP row, and the 0/1 masks discard whatever a shift
 // pulls in from a neighbouring candidate of the same row.
 template <int LPS, bool ISO, bool SLIDES, int MAXCH, int MAXCOL, int D0 = 0, int D1 = 0, int D2 = 0, int D3 = 0,
-          bool DIAG = false>
+          bool DIAG = false, bool MULTI = true>
 __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
   constexpr bool DPP = D0 != 0;
   static_assert(!DPP || ((D1 != 0 || D2 == 0) && (D2 != 0 || D3 == 0) && (D3 == 0 || MAXCH >= 4)),
@@ -476,8 +476,9 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
   // the generic kernels (MAXCH = 4) bound their child loops by the model's largest child count: a scalar
   // branch per slot; a skipped slot would have added exact zeros
   const int max_children = P.max_children;
-  // humanoid-shaped instantiations always carry multi-dof joints; the others ask the model (scalar branches)
-  const bool multi = (MAXCH == 3 && !SLIDES) || P.max_rot > 1;
+  // MULTI: some joint of the model has more than one hinge dof.  A template parameter, not a wave-uniform flag:
+  // around small blocks the compiler turns a uniform branch into selects and executes both sides.
+  constexpr bool multi = MULTI;
   auto child_slot = [&](int c) { return MAXCH <= 3 || c < max_children; };
   // DPP layout: 0/1 masks — rm[s]: this link has an s-th child (it sits at lane - Ds); pm[s]: this link is the
   // s-th child of its parent (which sits at lane + Ds)
