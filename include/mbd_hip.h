@@ -61,8 +61,9 @@ enum mbd_reward_kind {
   MBD_REW_HUMANOIDTRACK = 3, /* mbd/envs/humanoidtrack.py:87-96 (computed from the INCOMING state)   */
   MBD_REW_HUMANOIDSTANDUP = 4, /* mbd/envs/humanoidstandup.py:50-56                                   */
   MBD_REW_ANT = 6,           /* brax.envs.ant (absent): forward_reward + healthy_reward - ctrl_cost:
-                                p0*(x1-x0)/dt + (p2 <= z <= p3 ? p4 : 0) - p1*|a|^2, reward_params =
-                                (1, 0.5, 0.2, 1.0, 1.0) — recollection, unpinned                        */
+                                p0*(x1-x0)/dt + (p5 != 0 || p2 <= z <= p3 ? p4 : 0) - p1*|a|^2, reward_params =
+                                (1, 0.5, 0.2, 1.0, 1.0, 1) — p5 = terminate_when_unhealthy (stock: on, the
+                                healthy term is then a constant); recollection, unpinned                 */
   MBD_REW_CARTPOLE = 5       /* mbd/envs/cartpole.py:45: cos(q[1]) - |qd[0]| (hinge of link 1, slide of link 0) */
 };
 
@@ -151,7 +152,21 @@ int mbd_prng_split(const uint32_t key[2], int num, int impl, uint32_t* keys_out 
 /* ------------------------------------------------------------------------------------------------ */
 typedef struct mbd_env mbd_env;
 
-/* car2d needs no model; `env_name` must be "car2d" (mbd/envs/car2d.py:43-71).  xref = demo path
+/* get_env(env_name) (mbd/envs/__init__.py:13-33): a string in, an env out.  The compiled models ("sys" of
+ * humanoidrun.py:15, hopper.py:14, humanoidtrack.py:16, ...) and the demo trajectories (car2d.py:66,
+ * humanoidtrack.py:33-43) are constant data inside the library, so a C caller needs no Python and no MJCF
+ * compiler.  Names: car2d, hopper, halfcheetah, humanoidrun, humanoidtrack, walker2d, humanoidstandup, cartpole,
+ * ant.  "pushT" (generalized backend) and unknown names return MBD_ERR_UNSUPPORTED — the Python shim raises
+ * ValueError for both, like :33. */
+int mbd_env_create(const char* env_name, int device, mbd_env** out);
+/* the names mbd_env_create accepts: index 0, 1, ... until NULL (host only) */
+const char* mbd_env_name(int index);
+/* the embedded compiled model of a built-in rigid-body env (host only, no device needed) */
+int mbd_builtin_model(const char* env_name, mbd_model_t* model_out);
+
+/* The two constructors below take caller-supplied data instead (custom MJCF models compiled by
+ * mbd_hip/mjcf.py, other demo paths).
+ * car2d needs no model; `env_name` must be "car2d" (mbd/envs/car2d.py:43-71).  xref = demo path
  * [50][2] float32 (car2d_xref.npy cast to f32) or NULL when demos are not used. */
 int mbd_env_create_car2d(int device, const float* xref, mbd_env** out);
 /* rigid-body envs: humanoidrun / humanoidtrack / hopper / halfcheetah — the caller passes the
@@ -167,13 +182,31 @@ int mbd_env_info(const mbd_env* env, int* action_size, int* observation_size, in
 /* reset(rng) -> state (humanoidrun.py:19-32, hopper.py:20-34, humanoidtrack.py:48-61, car2d.py:73-75).
  * Host computation (forward kinematics once per run). state_out: float[state_size] HOST. */
 int mbd_env_reset(const mbd_env* env, const uint32_t key[2], int prng_impl, float* state_out);
-/* step(state, action) -> (state', reward) for ONE environment (rendering / verification path,
+/* step(state, action) -> (state', reward, obs) for ONE environment (rendering / verification path,
  * mbd_planner.py:163; utils.py:23-33).  Runs the same HIP rollout kernel with B=1,H=1; synchronous.
- * All pointers HOST. obs_out may be NULL. */
+ * All pointers HOST. reward_out / obs_out (float[observation_size], see mbd_env_observe) may be NULL. */
 int mbd_env_step(mbd_env* env, const float* state_in, const float* action, float* state_out,
                  float* reward_out, float* obs_out);
 /* rew_xref (car2d.py:71, humanoidtrack.py:44) */
 int mbd_env_rew_xref(const mbd_env* env, float* out);
+/* env.sys (mbd_planner.py:174; humanoidrun.py:15): a copy of the env's compiled model */
+int mbd_env_get_model(const mbd_env* env, mbd_model_t* model_out);
+/* env.xref (mbd_planner.py:167; car2d.py:66 [50][2], humanoidtrack.py:36-43 [n_track][50][3]) copied to the HOST
+ * buffer xref_out[capacity]; count_out = number of floats (0: the env has no demonstration). xref_out may be NULL. */
+int mbd_env_xref(const mbd_env* env, float* xref_out, int capacity, int* count_out);
+/* jax.vmap(env.eval_xref_logpd)(qs) (mbd_planner.py:118; humanoidtrack.py:98-106, car2d.py:95-102):
+ *   d_xpos      : [B][H][K][3] tracked link positions after every control step (car2d: [B][H][3] = q) — the
+ *                 d_xpos output of mbd_env_rollout
+ *   d_logpd_out : [B]
+ * H must be 50 (the demos have 50 rows). asynchronous on `stream`. */
+int mbd_env_xref_logpd(const mbd_env* env, const float* d_xpos, int B, int H, float* d_logpd_out, void* stream);
+/* _get_obs (humanoidrun.py:43-44, hopper.py:49-55, car2d.py:86; brax ant / half_cheetah) of ONE state:
+ * kinematics.inverse on the host (the planner never reads observations, mbd_planner.py:71 — API parity only).
+ * state: float[state_size] HOST; obs_out: float[observation_size] HOST. */
+int mbd_env_observe(const mbd_env* env, const float* state, float* obs_out);
+/* the same from a bare model, plus the generalized coordinates: q_out[n_q], qd_out[n_qd], obs_out — any may be
+ * NULL.  Pure host arithmetic, no device needed. */
+int mbd_model_observe(const mbd_model_t* model, const float* state, float* q_out, float* qd_out, float* obs_out);
 
 /* Batched rollout = jax.vmap(rollout_us, in_axes=(None,0)) (mbd_planner.py:109, utils.py:14-20).
  *   d_state0 : [state_size]        one initial state shared by all B candidates

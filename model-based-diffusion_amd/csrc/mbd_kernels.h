@@ -954,7 +954,9 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
       } else if (rkind == MBD_REW_HALFCHEETAH) {
         rew = rp0 * ((o1.x - o0.x) / dt_ctrl) - rp1 * ctrl_cost;
       } else if (rkind == MBD_REW_ANT) {
-        float healthy = (o1.z >= M->reward_params[2] && o1.z <= M->reward_params[3]) ? M->reward_params[4] : 0.0f;
+        // reward_params[5] != 0: terminate_when_unhealthy (the stock setting) — the healthy term is unconditional
+        float healthy = (M->reward_params[5] != 0.0f || (o1.z >= M->reward_params[2] && o1.z <= M->reward_params[3]))
+                            ? M->reward_params[4] : 0.0f;
         rew = (rp0 * ((o1.x - o0.x) / dt_ctrl) + healthy) - rp1 * ctrl_cost;
       } else if (rkind == MBD_REW_CARTPOLE) {
         rew = cart_cos - fabs_(cart_vs);

@@ -36,7 +36,8 @@ class PlanConfig(C.Structure):
 
 EXPORTS = [
     "mbd_last_error", "mbd_version", "mbd_device_count", "mbd_prng_key", "mbd_prng_split",
-    "mbd_env_create_car2d", "mbd_env_create_model", "mbd_env_destroy", "mbd_env_info", "mbd_env_reset",
+    "mbd_env_create", "mbd_env_name", "mbd_builtin_model", "mbd_env_get_model", "mbd_env_xref", "mbd_env_xref_logpd",
+    "mbd_env_observe", "mbd_model_observe", "mbd_env_create_car2d", "mbd_env_create_model", "mbd_env_destroy", "mbd_env_info", "mbd_env_reset",
     "mbd_env_step", "mbd_env_rew_xref", "mbd_env_rollout", "mbd_plan_create", "mbd_plan_destroy",
     "mbd_plan_schedule", "mbd_plan_set_state0", "mbd_plan_sample_rollout", "mbd_plan_score_update",
     "mbd_plan_set_sigma", "mbd_plan_get_sigma", "mbd_plan_reverse_once", "mbd_plan_run", "mbd_plan_eval", "mbd_plan_peek", "mbd_plan_kernel_time",
@@ -70,6 +71,15 @@ def load() -> C.CDLL:
     lib.mbd_device_count.argtypes = [C.POINTER(_i)]
     lib.mbd_prng_key.argtypes = [C.c_uint64, _u32p]
     lib.mbd_prng_split.argtypes = [_u32p, _i, _i, _u32p]
+    lib.mbd_env_create.argtypes = [C.c_char_p, _i, C.POINTER(_vp)]
+    lib.mbd_env_name.argtypes = [_i]
+    lib.mbd_env_name.restype = C.c_char_p
+    lib.mbd_builtin_model.argtypes = [C.c_char_p, C.POINTER(MbdModel)]
+    lib.mbd_env_get_model.argtypes = [_vp, C.POINTER(MbdModel)]
+    lib.mbd_env_xref.argtypes = [_vp, _vp, _i, C.POINTER(_i)]
+    lib.mbd_env_xref_logpd.argtypes = [_vp, _vp, _i, _i, _vp, _vp]
+    lib.mbd_env_observe.argtypes = [_vp, _vp, _vp]
+    lib.mbd_model_observe.argtypes = [C.POINTER(MbdModel), _vp, _vp, _vp, _vp]
     lib.mbd_env_create_car2d.argtypes = [_i, _vp, C.POINTER(_vp)]
     lib.mbd_env_create_model.argtypes = [C.c_char_p, _i, C.POINTER(MbdModel), _vp, _f, C.POINTER(_vp)]
     lib.mbd_env_destroy.argtypes = [_vp]

@@ -14,7 +14,7 @@ from typing import Any, Dict, Optional
 import numpy as np
 
 from .. import _capi
-from ..model import LINK_STATE, Model
+from ..model import LINK_STATE, MbdModel, Model
 from . import specs
 
 _ASSETS = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "assets")
@@ -37,6 +37,17 @@ class State:
 
     def replace(self, **kw) -> "State":
         return dataclasses.replace(self, **kw)
+
+
+def _names(env_name: str):
+    """Link / actuator names of a built-in model (diagnostics only; the numbers come from the library)."""
+    import json
+    try:
+        with open(os.path.join(_ASSETS, "compiled", f"{env_name}.json")) as f:
+            d = json.load(f)
+        return d["link_names"], d["actuator_names"]
+    except OSError:
+        return (), ()
 
 
 class _EnvBase:
@@ -65,17 +76,36 @@ class _EnvBase:
     def reset(self, rng) -> State:
         st = np.zeros(self._state_size, np.float32)
         _capi.check(self._lib.mbd_env_reset(self._h, _capi.key_array(rng), prng_impl(), _capi.np_ptr(st)))
-        return State(self._shape_state(st), None, np.float32(0.0), np.float32(0.0), {})
+        return State(self._shape_state(st), self.observe(st), np.float32(0.0), np.float32(0.0), {})
 
     def step(self, state: State, action) -> State:
         s_in = np.ascontiguousarray(state.pipeline_state, np.float32).reshape(-1)
         a = np.ascontiguousarray(action, np.float32).reshape(-1)
         s_out = np.zeros_like(s_in)
         rew = np.zeros(1, np.float32)
+        obs = np.zeros(self.observation_size, np.float32)
         _capi.check(self._lib.mbd_env_step(self._h, _capi.np_ptr(s_in), _capi.np_ptr(a), _capi.np_ptr(s_out),
-                                           _capi.np_ptr(rew), None))
-        return state.replace(pipeline_state=self._shape_state(s_out), reward=rew[0],
+                                           _capi.np_ptr(rew), _capi.np_ptr(obs)))
+        return state.replace(pipeline_state=self._shape_state(s_out), obs=obs, reward=rew[0],
                              done=self._next_done(state))
+
+    def observe(self, pipeline_state) -> np.ndarray:
+        """_get_obs of one state through the C ABI (host arithmetic inside the library)."""
+        st = np.ascontiguousarray(pipeline_state, np.float32).reshape(-1)
+        obs = np.zeros(self.observation_size, np.float32)
+        _capi.check(self._lib.mbd_env_observe(self._h, _capi.np_ptr(st), _capi.np_ptr(obs)))
+        return obs
+
+    def eval_xref_logpd_batch(self, xpos):
+        """jax.vmap(env.eval_xref_logpd)(qs) (mbd_planner.py:118) on the GPU: ``xpos`` [B,H,K,3] (car2d: [B,H,3])
+        CUDA tensor as returned by ``rollout(..., want_xpos=True)`` -> [B] CUDA tensor."""
+        import torch
+        dev = torch.device("cuda", self.device)
+        x = torch.as_tensor(xpos, dtype=torch.float32, device=dev).contiguous()
+        out = torch.empty(x.shape[0], dtype=torch.float32, device=dev)
+        stream = torch.cuda.current_stream(dev).cuda_stream
+        _capi.check(self._lib.mbd_env_xref_logpd(self._h, x.data_ptr(), x.shape[0], x.shape[1], out.data_ptr(), stream))
+        return out
 
     def _next_done(self, state):
         return np.float32(0.0)
@@ -114,11 +144,12 @@ class Car2d(_EnvBase):
         self._lib = _capi.load()
         self.device = device
         self.H = 50
-        self.xref = np.load(os.path.join(_ASSETS, "compiled", "car2d_xref.npy")).astype(np.float32)
         h = C.c_void_p()
-        _capi.check(self._lib.mbd_env_create_car2d(device, _capi.np_ptr(self.xref), C.byref(h)))
+        _capi.check(self._lib.mbd_env_create(b"car2d", device, C.byref(h)))
         self._h = h
         self._info()
+        self.xref = np.zeros((50, 2), np.float32)  # car2d.py:66
+        _capi.check(self._lib.mbd_env_xref(self._h, _capi.np_ptr(self.xref), 100, None))
         rx = C.c_float()
         _capi.check(self._lib.mbd_env_rew_xref(self._h, C.byref(rx)))
         self.rew_xref = rx.value
@@ -132,12 +163,7 @@ class Car2d(_EnvBase):
         return (3,)
 
     def reset(self, rng=None) -> State:
-        st = super().reset(np.zeros(2, np.uint32) if rng is None else rng)
-        return st.replace(obs=st.pipeline_state.copy())
-
-    def step(self, state: State, action) -> State:  # car2d.py:86: obs = q
-        st = super().step(state, action)
-        return st.replace(obs=np.asarray(st.pipeline_state).copy())
+        return super().reset(np.zeros(2, np.uint32) if rng is None else rng)
 
     def eval_xref_logpd(self, xs) -> np.float32:
         """car2d.py:95-102 for ONE trajectory xs [H,3] (host; the planner uses the batched kernel)."""
@@ -154,26 +180,38 @@ class RigidBodyEnv(_EnvBase):
         self.device = device
         self.env_name = env_name
         spec = specs.SPECS[env_name]
-        if model is None:
-            with open(os.path.join(_ASSETS, "compiled", f"{env_name}.json")) as f:
-                model = Model.from_json(f.read())
-        self.sys = model
-        self._struct = model.to_struct()
-        self.xref = None
-        self.rew_xref = 0.0
-        xref_ptr = None
-        if env_name == "humanoidtrack":
-            self.H = 50  # humanoidtrack.py:17
-            self.xref = np.ascontiguousarray(np.load(os.path.join(_ASSETS, "compiled", "jog_xref.npy")), np.float32)
-            self.rew_xref = 1.0  # humanoidtrack.py:44
-            self.track_body_names = list(spec["track"])
-            self.track_body_idx = np.asarray(model.fields["track_link"], np.int32)
-            xref_ptr = _capi.np_ptr(self.xref)
         h = C.c_void_p()
-        _capi.check(self._lib.mbd_env_create_model(env_name.encode(), device, C.byref(self._struct), xref_ptr,
-                                                   self.rew_xref, C.byref(h)))
+        if model is None:
+            # by name, like mbd.envs.get_env: the compiled model and the demo live inside the library
+            _capi.check(self._lib.mbd_env_create(env_name.encode(), device, C.byref(h)))
+        else:  # a caller-compiled model (mbd_hip.mjcf.load): custom MJCF files, experiments
+            xref_ptr, rew_xref = None, 0.0
+            if env_name == "humanoidtrack":
+                xr = np.ascontiguousarray(np.load(os.path.join(_ASSETS, "compiled", "jog_xref.npy")), np.float32)
+                xref_ptr, rew_xref = _capi.np_ptr(xr), 1.0  # humanoidtrack.py:44
+            st = model.to_struct()
+            _capi.check(self._lib.mbd_env_create_model(env_name.encode(), device, C.byref(st), xref_ptr, rew_xref,
+                                                       C.byref(h)))
         self._h = h
         self._info()
+        st = MbdModel()
+        _capi.check(self._lib.mbd_env_get_model(self._h, C.byref(st)))
+        names = (model.link_names, model.actuator_names) if model is not None else _names(env_name)
+        self.sys = Model.from_struct(st, *names, env_name=env_name)  # env.sys (mbd_planner.py:174)
+        self._struct = st
+        self.xref = None
+        n = C.c_int()
+        _capi.check(self._lib.mbd_env_xref(self._h, None, 0, C.byref(n)))
+        if n.value:  # env.xref (humanoidtrack.py:36-43): [n_track][50][3]
+            self.xref = np.zeros((int(st.n_track), 50, 3), np.float32)
+            _capi.check(self._lib.mbd_env_xref(self._h, _capi.np_ptr(self.xref), n.value, None))
+        rx = C.c_float()
+        _capi.check(self._lib.mbd_env_rew_xref(self._h, C.byref(rx)))
+        self.rew_xref = rx.value
+        if env_name == "humanoidtrack":
+            self.H = 50  # humanoidtrack.py:17
+            self.track_body_names = list(spec["track"])
+            self.track_body_idx = np.asarray(self.sys.fields["track_link"], np.int32)
 
     def _shape_state(self, st):
         return st.reshape(self.sys.n_links, LINK_STATE)
@@ -187,68 +225,21 @@ class RigidBodyEnv(_EnvBase):
 
     # ---- kinematics.inverse on the host (observations only; the planner never reads obs) ---------------
     def generalized(self, pipeline_state):
-        """(q, qd) from a [L,13] COM-frame state: free root = link-frame pose / velocity; slides = anchor
-        offset / relative anchor velocity along the slide axes; hinges = joint-frame Euler angles (x, y', z'')
-        times the MJCF axis handedness and the relative angular velocity projected on the gimbal axes."""
-        from ..mjcf import _q2mat, _qmul
-        F = self.sys.fields
-        s = np.asarray(pipeline_state, np.float64).reshape(-1, LINK_STATE)
-        q = np.zeros(self.sys.q_size())
-        qd = np.zeros(self.sys.qd_size())
-        for l in range(self.sys.n_links):
-            p, r, v, w = s[l, :3], s[l, 3:7], s[l, 7:10], s[l, 10:13]
-            R = _q2mat(r)
-            qi, di = int(F["q_idx"][l]), int(F["qd_idx"][l])
-            if F["n_rot"][l] < 0:
-                c = R @ np.asarray(F["com"][l], float)
-                q[qi:qi + 3], q[qi + 3:qi + 7] = p - c, r
-                qd[di:di + 3], qd[di + 3:di + 6] = v - np.cross(w, c), w
-                continue
-            par = int(F["parent"][l])
-            if par >= 0:
-                Pp, Pr, Pv, Pw = s[par, :3], s[par, 3:7], s[par, 7:10], s[par, 10:13]
-            else:
-                Pp, Pr, Pv, Pw = np.zeros(3), np.array([1.0, 0, 0, 0]), np.zeros(3), np.zeros(3)
-            RP = _q2mat(Pr)
-            ap = Pp + RP @ np.asarray(F["ap_pos"][l], float)
-            ac = p + R @ np.asarray(F["ac_pos"][l], float)
-            A = _q2mat(_qmul(Pr, np.asarray(F["ap_rot"][l], float)))
-            Cm = _q2mat(_qmul(r, np.asarray(F["ac_rot"][l], float)))
-            Xp, Yp, Zp = A[:, 0], A[:, 1], A[:, 2]
-            Xc, Yc, Zc = Cm[:, 0], Cm[:, 1], Cm[:, 2]
-            ang = [np.arctan2(-Zc @ Yp, Zc @ Zp), np.arcsin(np.clip(Zc @ Xp, -1, 1)), np.arctan2(-Yc @ Xp, Xc @ Xp)]
-            n1 = np.cross(Zc, Xp)
-            axes = [Xp, n1 / (np.linalg.norm(n1) + 1e-12), Zc]
-            rel_w = w - Pw
-            rel_v = (v + np.cross(w, ac - p)) - (Pv + np.cross(Pw, ap - Pp))
-            ns, nr = int(F["n_slide"][l]), int(F["n_rot"][l])
-            for k in range(ns):
-                sk = A @ np.asarray(F["slide_axis"][l][k], float)
-                q[qi + k], qd[di + k] = (ac - ap) @ sk, rel_v @ sk
-            for k in range(nr):
-                sg = float(F["rot_sign"][l][k])
-                q[qi + ns + k], qd[di + ns + k] = sg * ang[k], sg * (rel_w @ axes[k])
-        return q.astype(np.float32), qd.astype(np.float32)
+        """(q, qd) from a [L,13] COM-frame state (mbd_model_observe, host arithmetic inside the library): free
+        root = link-frame pose / velocity; slides = anchor offset / relative anchor velocity along the slide axes;
+        hinges = joint-frame Euler angles (x, y', z'') times the MJCF axis handedness and the relative angular
+        velocity projected on the gimbal axes."""
+        st = np.ascontiguousarray(pipeline_state, np.float32).reshape(-1)
+        q, qd = np.zeros(self.sys.q_size(), np.float32), np.zeros(self.sys.qd_size(), np.float32)
+        _capi.check(self._lib.mbd_model_observe(C.byref(self._struct), _capi.np_ptr(st), _capi.np_ptr(q),
+                                                _capi.np_ptr(qd), None))
+        return q, qd
 
     def _get_obs(self, pipeline_state) -> np.ndarray:
-        q, qd = self.generalized(pipeline_state)
-        if self.env_name in ("hopper", "walker2d"):  # hopper.py:49-55 / walker2d.py:49-55
-            pos = q.copy()
-            pos[1] = self.link_positions(pipeline_state)[0, 2]
-            return np.concatenate([pos, np.clip(qd, -10, 10)]).astype(np.float32)
-        if self.env_name == "ant":  # brax ant: root x, y excluded
-            return np.concatenate([q[2:], qd]).astype(np.float32)
-        if self.env_name == "halfcheetah":  # brax half_cheetah: the root x position is excluded
-            return np.concatenate([q[1:], qd]).astype(np.float32)
-        return np.concatenate([q, qd]).astype(np.float32)  # humanoidrun.py:43-44 etc.
-
-    def reset(self, rng) -> State:
-        st = super().reset(rng)
-        return st.replace(obs=self._get_obs(st.pipeline_state))
-
-    def step(self, state: State, action) -> State:
-        st = super().step(state, action)
-        return st.replace(obs=self._get_obs(st.pipeline_state))
+        st = np.ascontiguousarray(pipeline_state, np.float32).reshape(-1)
+        obs = np.zeros(self.observation_size, np.float32)
+        _capi.check(self._lib.mbd_model_observe(C.byref(self._struct), _capi.np_ptr(st), None, None, _capi.np_ptr(obs)))
+        return obs
 
     @property
     def observation_size(self) -> int:

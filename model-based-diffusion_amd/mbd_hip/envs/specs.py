@@ -22,13 +22,17 @@ SPECS = {
                      init_q_offset=(0.0, 3.141592653589793)),
     # brax.envs.ant (absent; selected by name at mbd/envs/__init__.py:30-31 and the DEFAULT env_name of Args,
     # mbd_planner.py:25): positional backend dt 0.005, n_frames 10, reset noise 0.1 (uniform q, normal qd),
-    # reward = forward velocity + healthy(1.0 while 0.2 <= z <= 1.0) - 0.5 |a|^2 — recollection, unpinned
+    # reward = forward velocity + healthy_reward - 0.5 |a|^2.  With the stock terminate_when_unhealthy=True the
+    # healthy term is the CONSTANT healthy_reward (the z-range only sets `done`, which the planner never reads):
+    # reward_params[5] = 1 selects that; 0 gives healthy_reward * (0.2 <= z <= 1.0).  The env class also replaces
+    # every actuator gear by 200 on the positional backend.  Recollection of brax.envs.ant, unpinned.
     "ant": dict(xml="ant.xml", from_reference=False, n_frames=10, reset_noise=0.1,
-                reward_params=(1.0, 0.5, 0.2, 1.0, 1.0)),
+                reward_params=(1.0, 0.5, 0.2, 1.0, 1.0, 1.0), gear_override=(200.0,) * 8),
     # brax.envs.half_cheetah (absent): n_frames 16 @ 0.003125 s, reset noise 0.1, forward_reward_weight 1,
-    # ctrl_cost_weight 0.1 — recollection, unpinned
+    # ctrl_cost_weight 0.1; spring/positional backends replace the gears by [120, 90, 60, 120, 100, 100]
+    #  — recollection, unpinned
     "halfcheetah": dict(xml="halfcheetah.xml", from_reference=False, n_frames=16, reset_noise=0.1,
-                        reward_params=(1.0, 0.1)),
+                        reward_params=(1.0, 0.1), gear_override=(120.0, 90.0, 60.0, 120.0, 100.0, 100.0)),
 }
 
 # names mbd.envs.get_env knows (mbd/envs/__init__.py:13-33) that are outside the hot-path scope

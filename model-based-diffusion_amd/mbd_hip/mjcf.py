@@ -233,7 +233,7 @@ def _fuse(b: _Body) -> None:
 def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Optional[str] = None,
          track_names: Sequence[str] = (), reset_noise: float = 0.0,
          reward_params: Sequence[float] = (), dt_override: Optional[float] = None,
-         init_q_offset: Sequence[float] = ()) -> Model:
+         init_q_offset: Sequence[float] = (), gear_override: Sequence[float] = ()) -> Model:
     """Compile an MJCF file. ``n_frames`` is the env's physics substeps per control step
     (humanoidrun.py:17 -> 7, humanoidtrack.py:46 -> 5, hopper.py:18 -> 20)."""
     root = ET.parse(path).getroot()
@@ -457,6 +457,10 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
             act_lo.append(lo); act_hi.append(hi); act_names.append(a.get("name", a["joint"]))
     if len(act_link) > MAX_ACT:
         raise ValueError("too many actuators")
+    if len(gear_override):  # the env class replaces sys.actuator.gear (brax ant / half_cheetah, positional backend)
+        if len(gear_override) != len(act_gear):
+            raise ValueError(f"gear_override has {len(gear_override)} entries for {len(act_gear)} actuators")
+        act_gear = [math.copysign(float(g), old) for g, old in zip(gear_override, act_gear)]
     for k, off in enumerate(init_q_offset):
         init_q[k] += float(off)
     names = [ent["body"].name for ent in links]

@@ -103,6 +103,22 @@ class Model:
             view[...] = src
         return s
 
+    @staticmethod
+    def from_struct(st: MbdModel, link_names: List[str] = (), actuator_names: List[str] = (),
+                    env_name: str = "") -> "Model":
+        """The inverse of ``to_struct``: arrays trimmed to the model's own sizes (what ``from_json`` yields)."""
+        L, A, K, T, Q = st.n_links, st.n_act, st.n_col, st.n_track, st.n_q
+        lead = {"act_link": A, "act_slot": A, "act_gear": A, "act_lo": A, "act_hi": A, "col_link": K, "col_pos": K,
+                "col_radius": K, "track_link": T, "init_q": Q, "gravity": 3, "reward_params": 8}
+        fields: Dict[str, Any] = {}
+        for name in _SCALARS:
+            fields[name] = getattr(st, name)
+        for name in _ARRAYS:
+            a = np.ctypeslib.as_array(getattr(st, name)).copy()
+            fields[name] = a[: lead.get(name, L)]
+        return Model(fields, list(link_names) or [f"link{l}" for l in range(L)],
+                     list(actuator_names) or [f"act{a}" for a in range(A)], env_name)
+
     def to_json(self) -> str:
         out = {"env_name": self.env_name, "link_names": self.link_names,
                "actuator_names": self.actuator_names, "fields": {}}

@@ -23,7 +23,7 @@ from ..planners.mbd_planner import Plan, apply_recommended
 
 @dataclass
 class Args:
-    algo: str = "mbd"  # only "mbd" is on the hot path ("path_integral" is SURVEY §8(f) N2)
+    algo: str = "mbd"  # path_integral, mbd
     update_method: str = "mppi"
     mode: str = "seed"  # "seed" | "temp"
     env_name: str = "ant"
@@ -78,10 +78,30 @@ def run_concurrent(plan_args, device: int = 0):
     return rews, mus, secs
 
 
+def _run_path_integral_seq(arg_list, device):
+    """The path-integral baselines (run_mbd.py:22-26,46-50) run one plan after another, each timed end to end like
+    the reference does (`time()` around the call, :21,34)."""
+    from ..planners import path_integral
+    rews, times = [], []
+    for a in arg_list:
+        t0 = time.time()
+        rews.append(path_integral.run_path_integral(a, device=device))
+        times.append(time.time() - t0)
+    return np.array(rews), np.array(times)
+
+
 def run_multiple_seed(args: Args, device: int = 0, **plan_kw):
     """run_mbd.py:17-39: seeds 0..7, mean +- std of the final reward and the time."""
+    if args.algo == "path_integral":  # :22-26
+        from ..planners import path_integral
+        rews, times = _run_path_integral_seq(
+            [path_integral.Args(seed=seed, env_name=args.env_name, update_method=args.update_method, **plan_kw)
+             for seed in range(8)], device)
+        print(f"rew: {rews.mean():.2f} \\pm {rews.std():.2f}")
+        print(f"time: {times.mean():.2f} \\pm {times.std():.2f}")
+        return rews, float(times.sum())
     if args.algo != "mbd":
-        raise NotImplementedError("only algo='mbd' is implemented on the MI355X hot path")
+        raise NotImplementedError  # :32-33
     plans = [mbd_planner.Args(seed=seed, env_name=args.env_name, not_render=True, **plan_kw) for seed in range(8)]
     rews, _, secs = run_concurrent(plans, device)
     rews = np.array(rews)
@@ -91,14 +111,20 @@ def run_multiple_seed(args: Args, device: int = 0, **plan_kw):
 
 
 def run_multiple_temp(args: Args, device: int = 0, **plan_kw):
-    """run_mbd.py:42-64: temperature sweep at seed 0 with recommended params disabled."""
-    if args.algo != "mbd":
-        raise NotImplementedError("only algo='mbd' is implemented on the MI355X hot path")
+    """run_mbd.py:42-64: temperature sweep at seed 0 (mbd: recommended params disabled; path_integral: the
+    reference neither disables them nor forwards update_method, :46-50 — replicated, not "fixed")."""
     temps = np.array([0.01, 0.03, 0.06, 0.1, 0.2, 0.4, 0.6, 0.8])
-    plans = [mbd_planner.Args(seed=0, env_name=args.env_name, temp_sample=float(t), not_render=True,
-                              disable_recommended_params=True, **plan_kw) for t in temps]
-    rews, _, secs = run_concurrent(plans, device)
-    rews = np.array(rews)
+    if args.algo == "path_integral":
+        from ..planners import path_integral
+        rews, _ = _run_path_integral_seq(
+            [path_integral.Args(seed=0, env_name=args.env_name, temp_sample=float(t), **plan_kw) for t in temps], device)
+    elif args.algo == "mbd":
+        plans = [mbd_planner.Args(seed=0, env_name=args.env_name, temp_sample=float(t), not_render=True,
+                                  disable_recommended_params=True, **plan_kw) for t in temps]
+        rews, _, _ = run_concurrent(plans, device)
+        rews = np.array(rews)
+    else:
+        raise NotImplementedError
     best_temp = temps[np.argmax(rews)]
     print(f"rews: {rews}")
     print(f"best_temp: {best_temp:.2f}")

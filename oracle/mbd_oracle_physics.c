@@ -504,7 +504,9 @@ static real env_step(const mbd_model_t* m, xf_t* x, mo_t* xd, const float* actio
       real ctrl = 0;
       for (int a = 0; a < m->n_act; ++a) ctrl += R(action[a]) * R(action[a]);
       real dtc = R(m->dt) * (real)m->n_frames;
-      real healthy = (o1[2] >= R(m->reward_params[2]) && o1[2] <= R(m->reward_params[3])) ? R(m->reward_params[4]) : R(0);
+      /* reward_params[5] != 0: terminate_when_unhealthy (brax's default) makes the healthy term unconditional */
+      real healthy = (m->reward_params[5] != 0.0f || (o1[2] >= R(m->reward_params[2]) && o1[2] <= R(m->reward_params[3])))
+                         ? R(m->reward_params[4]) : R(0);
       return (R(m->reward_params[0]) * ((o1[0] - o0[0]) / dtc) + healthy) - R(m->reward_params[1]) * ctrl;
     }
     case MBD_REW_CARTPOLE: { /* cartpole.py:45: cos(q[1]) - |qd[0]|: hinge angle of link 1, slide velocity of link 0 */

@@ -85,6 +85,51 @@ def test_get_env_errors_like_the_reference(lib):
             get_env("car2d")
 
 
+def test_builtin_models_are_the_compiled_assets(lib):
+    """mbd_env_create(name) needs no Python: the library embeds every compiled model (tools/gen_models_inc.py).
+    Host-only accessors: the names it knows and, bit for bit, the models it would create."""
+    from mbd_hip.envs import specs
+    from mbd_hip.model import MbdModel
+    names, k = [], 0
+    while True:
+        n = lib.mbd_env_name(k)
+        if n is None:
+            break
+        names.append(n.decode())
+        k += 1
+    assert names[0] == "car2d" and sorted(names[1:]) == sorted(specs.SPECS)
+    for name in specs.SPECS:
+        st = MbdModel()
+        assert lib.mbd_builtin_model(name.encode(), C.byref(st)) == 0
+        assert bytes(st) == bytes(load_model(name).to_struct()), name
+    st = MbdModel()
+    assert lib.mbd_builtin_model(b"pushT", C.byref(st)) == -2
+
+
+def test_create_by_name_errors(lib):
+    """Unknown / out-of-scope names are rejected before a device is looked for (-> ValueError in the shim, like
+    mbd/envs/__init__.py:33); known names fail LOUDLY without a device."""
+    from mbd_hip import _capi
+    lib.mbd_last_error.restype = C.c_char_p
+    h = C.c_void_p()
+    assert lib.mbd_env_create(b"no_such_env", 0, C.byref(h)) == _capi.MBD_ERR_UNSUPPORTED
+    assert b"Unknown environment: no_such_env" in lib.mbd_last_error()
+    assert lib.mbd_env_create(b"pushT", 0, C.byref(h)) == _capi.MBD_ERR_UNSUPPORTED
+    assert lib.mbd_env_create(None, 0, C.byref(h)) == _capi.MBD_ERR_INVALID
+    if _capi.device_count() == 0:
+        for name in (b"humanoidrun", b"car2d", b"hopper"):
+            assert lib.mbd_env_create(name, 0, C.byref(h)) == _capi.MBD_ERR_NO_DEVICE
+
+
+def test_model_from_struct_round_trip():
+    from mbd_hip.model import Model
+    for name in ("humanoidtrack", "hopper", "ant"):
+        m = load_model(name)
+        m2 = Model.from_struct(m.to_struct(), m.link_names, m.actuator_names, name)
+        assert bytes(m2.to_struct()) == bytes(m.to_struct())
+        assert np.array_equal(m2.init_q, m.init_q) and len(m2.fields["track_link"]) == m.fields["n_track"]
+
+
 def test_product_does_not_import_the_oracle():
     pkg = os.path.join(ROOT, "model-based-diffusion_amd")
     for dirpath, _, files in os.walk(pkg):
@@ -134,6 +179,9 @@ def test_c_abi_argument_errors_without_a_device(lib):
     assert lib.mbd_plan_sample_rollout(None, 1, None, None, None, None, None) == INVALID
     assert lib.mbd_plan_score_update(None, 1, None, None, None, None, None, None, None) == INVALID
     assert lib.mbd_env_create_model(None, 0, None, None, C.c_float(0), None) == INVALID
+    assert lib.mbd_env_xref_logpd(None, None, 1, 50, None, None) == INVALID
+    assert lib.mbd_env_observe(None, None, None) == INVALID and lib.mbd_model_observe(None, None, None, None, None) == INVALID
+    assert lib.mbd_env_get_model(None, None) == INVALID and lib.mbd_env_xref(None, None, 0, None) == INVALID
     assert lib.mbd_env_destroy(None) == 0 and lib.mbd_plan_destroy(None) == 0
     n = C.c_int(-1)
     assert lib.mbd_device_count(C.byref(n)) == 0 and n.value >= 0

@@ -41,7 +41,8 @@ def main():
         m = mjcf.load(path, env_name=name, n_frames=spec["n_frames"], drop_link_suffix=spec.get("drop_suffix"),
                       track_names=spec.get("track", ()), reset_noise=spec["reset_noise"],
                       reward_params=spec.get("reward_params", ()), dt_override=spec.get("dt_override"),
-                      init_q_offset=spec.get("init_q_offset", ()))
+                      init_q_offset=spec.get("init_q_offset", ()),
+                      gear_override=spec.get("gear_override", ()))
         with open(os.path.join(out, f"{name}.json"), "w") as f:
             f.write(m.to_json())
         print(f"{name}: L={m.n_links} nq={m.q_size()} nqd={m.qd_size()} nu={m.act_size()} "

@@ -7,6 +7,7 @@ import torch
 from mbd_hip import _capi
 from mbd_hip.envs import get_env
 lib = _capi.load()
+lib.mbd_debug_set_clock_buffer.argtypes = [C.c_void_p, C.c_void_p]
 env = get_env("humanoidrun")
 st = env.reset(_capi.prng_key(0))
 for N in (1024, 2048, 4096, 8192):
@@ -14,10 +15,10 @@ for N in (1024, 2048, 4096, 8192):
     env.rollout(st, us); torch.cuda.synchronize()
     G = N // 4
     buf = torch.zeros(G * 3, dtype=torch.int64, device="cuda")
-    lib.mbd_debug_set_clock_buffer(C.c_void_p(buf.data_ptr()))
+    lib.mbd_debug_set_clock_buffer(env.handle, C.c_void_p(buf.data_ptr()))
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(); env.rollout(st, us); e1.record(); torch.cuda.synchronize()
-    lib.mbd_debug_set_clock_buffer(None)
+    lib.mbd_debug_set_clock_buffer(env.handle, None)
     b = buf.cpu().numpy().reshape(G, 3)
     t0, t1, hw = b[:, 0], b[:, 1], b[:, 2]
     tick = 1e-8  # s_memtime: 100 MHz
