@@ -1,17 +1,31 @@
 #!/usr/bin/env python3
 """bench.py — diffusion-steps/sec of the reverse-diffusion hot path (BASELINE.json metric).
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--config C] [--scaling strong|weak]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
 A "step" is one reverse-diffusion step (mbd_planner.py:97-135): sample N candidates, roll them out
-H=50 control steps through the positional rigid-body simulator, score, softmax, weighted mean.
-Workload at one GPU = the configuration the metric is quoted on: humanoidrun, N=1024, H=50,
-Ndiffuse=100, temp 0.1, seed 0, disable_recommended_params.  With G GPUs the
-candidates are sharded: 1024 per GPU (weak scaling, N_total = 1024*G), one all-gather of the N mean
-rewards per step.  `value` is the whole-job rate in units of 1024-candidate diffusion steps per second
-(= plain diffusion-steps/sec at G=1); the un-normalised loop rate is reported as `steps_per_sec`.
+H control steps through the positional rigid-body simulator, score, softmax, weighted mean — PLUS the
+host read of the step's mean reward that the reference's progress bar forces every step
+(mbd_planner.py:147; SURVEY.md §8(d) defines the metric with that sync inside).  `value` is measured
+with the per-step read; `value_async` (same K steps, reads dropped) is reported beside it.
+
+--config (default `metric`, the configuration BASELINE.json's metric is quoted on):
+   metric            humanoidrun  N=1024 H=50 temp 0.1
+   hopper512         hopper       N=512  H=50 temp 0.1   (BASELINE config 2)
+   halfcheetah1024   halfcheetah  N=1024 H=50 temp 0.4   (config 3)
+   humanoidrun4096   humanoidrun  N=4096 H=50 temp 0.1   (config 4)
+   humanoidtrack2048demo  humanoidtrack N=2048 H=50 temp 0.1 enable_demo (config 5)
+   car2d             car2d        N=128  H=30 Ndiffuse=50 (config 1)
+Ndiffuse=100, seed 0, disable_recommended_params everywhere.
+
+--scaling with G > 1 GPUs (candidates are sharded over ranks, ONE all-gather of the N mean rewards per step):
+   strong (default)  N_total = the config's N, N/G candidates per GPU — the literal metric ("N=1024 at 1/2/4/8
+                     GPUs").  A rollout is latency-bound (time ~ instructions per wavefront, not wavefronts), so
+                     this curve is expected to be flat; it is reported as measured.
+   weak              N candidates PER GPU, N_total = N*G; `value` is then normalised to N-candidate steps.
+Both are measured in every multi-GPU run; the one not selected is reported under "other_scaling".
 Inputs are resident in HBM when the timed region starts; data is synthetic (seeded PRNG).
 """
 import argparse
@@ -26,81 +40,136 @@ for p in (ROOT, os.path.join(ROOT, "model-based-diffusion_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
-N_PER_GPU = int(os.environ.get("MBD_BENCH_N", "1024"))  # 1024 = the metric config; other values: experiments only
-H, ND, TEMP, ENV = 50, 100, 0.1, "humanoidrun"
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+VALU_PEAK_TF = 157.3   # MI355X_MICROARCH.md: vector FP32 peak
+ROUND = "r02"
+
+CONFIGS = {
+    # name: env, N, H, Ndiffuse, temp, demo, lanes per candidate (rollout kernel), kernel label
+    "metric": dict(env="humanoidrun", N=1024, H=50, Nd=100, temp=0.1, demo=False, lps=16,
+                   kernel="rollout_kernel<16,iso,noslide,3,1,dpp(1,-4,-6)>"),
+    "hopper512": dict(env="hopper", N=512, H=50, Nd=100, temp=0.1, demo=False, lps=4,
+                      kernel="rollout_kernel<4,aniso-diag,slides,dpp(1)>"),
+    "halfcheetah1024": dict(env="halfcheetah", N=1024, H=50, Nd=100, temp=0.4, demo=False, lps=8,
+                            kernel="rollout_kernel<8,iso,slides,dpp(1,-3)>"),
+    "humanoidrun4096": dict(env="humanoidrun", N=4096, H=50, Nd=100, temp=0.1, demo=False, lps=16,
+                            kernel="rollout_kernel<16,iso,noslide,3,1,dpp(1,-4,-6)>"),
+    "humanoidtrack2048demo": dict(env="humanoidtrack", N=2048, H=50, Nd=100, temp=0.1, demo=True, lps=16,
+                                  kernel="rollout_kernel<16,iso,noslide,3,1,dpp(1,-4,-6)>"),
+    "car2d": dict(env="car2d", N=128, H=30, Nd=50, temp=0.1, demo=False, lps=1, kernel="car2d_rollout_kernel"),
+}
 
 
 def b_alg_bytes(N, Hh, Nu, demo=False):
     """ALGORITHMIC bytes of one diffusion step: write+read Y0s, write+read rews,
-    read Ybar_i, write Ybar_{i-1}."""
+    read Ybar_i, write Ybar_{i-1} (+ the demo log-densities)."""
     return 4 * (2 * N * Hh * Nu + 2 * N + 2 * Hh * Nu) + (8 * N if demo else 0)
 
 
-def pmc_traffic():
-    """HBM bytes per rollout-kernel launch from the newest committed PMC pass (profiles/rNN_pmc.json,
-    FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950); None when absent."""
+def committed(name):
+    """A committed evidence file of the newest round under profiles/ (None when absent)."""
     import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc.json")))
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{name}")))
     if not files:
         return None, None
     with open(files[-1]) as f:
-        d = json.load(f)
-    for k, v in d.items():
-        if "rollout_kernel<16" in k and "hbm_bytes_per_launch_corrected" in v:
-            return v["hbm_bytes_per_launch_corrected"], os.path.basename(files[-1])
+        return json.load(f), os.path.basename(files[-1])
+
+
+def pmc_traffic(config):
+    """HBM bytes per rollout-kernel launch from the newest committed PMC pass (profiles/rNN_pmc.json, one entry per
+    bench config; FETCH_SIZE doubled as MI355X_MICROARCH.md §HBM prescribes for gfx950); None when absent."""
+    d, src = committed("pmc.json")
+    if not d:
+        return None, None
+    ent = d.get(config) or (d if config == "metric" else {})
+    for k, v in ent.items():
+        if isinstance(v, dict) and "rollout_kernel" in k and "hbm_bytes_per_launch_corrected" in v:
+            return v["hbm_bytes_per_launch_corrected"], src
     return None, None
 
 
-def valu_view(kern_ms, n_waves, substeps):
-    """FP32 VALU view of the same kernel (the limit that actually binds): static flops per lane per
-    substep from tools/count_flops.py (profiles/rNN_static_flops.json) x lanes x substeps / duration,
-    against the 157.3 TFLOP/s vector-FP32 peak of MI355X_MICROARCH.md."""
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_static_flops.json")))
-    if not files or kern_ms <= 0:
+def op_counts(env_name):
+    """F_sub(model): flops of one substep from the op counter compiled into the CPU restatement
+    (oracle/count_ops.cc), as committed by tools/count_ops.py under profiles/."""
+    d, src = committed("op_counts.json")
+    if d and env_name in d:
+        return d[env_name], src
+    return None, None
+
+
+def valu_view(cfg, n_local, kern_ms, n_frames, fsub, fsub_src):
+    """FP32 VALU view of the rollout kernel (the limit that binds): ALGORITHMIC flops = candidates x H x n_frames x
+    F_sub (op counter, real links and contacts only) against the 157.3 TFLOP/s vector peak; `issued` = the same
+    with the flops the emitted ISA executes per lane (tools/count_flops.py: padding lanes and masked slots
+    included)."""
+    if kern_ms <= 0 or cfg["lps"] <= 1:
         return None
-    with open(files[-1]) as f:
-        d = json.load(f)
-    flops = d["fp32_flops_per_lane_substep"] * 64.0 * n_waves * substeps
-    tf = flops / (kern_ms * 1e-3) / 1e12
-    return {"bound": "fp32-valu-issue", "achieved": tf, "peak": 157.3, "unit": "TFLOP/s", "frac": tf / 157.3,
-            "flops_per_launch": flops, "valu_instr_per_wave_substep": d["valu_per_substep"],
-            "waves": n_waves, "simds_occupied_frac": min(1.0, n_waves / 1024.0),
-            "source": os.path.basename(files[-1])}
+    waves = (n_local + 64 // cfg["lps"] - 1) // (64 // cfg["lps"])
+    substeps = cfg["H"] * n_frames
+    out = {"bound": "fp32-valu-issue", "peak": VALU_PEAK_TF, "unit": "TFLOP/s", "waves": waves,
+           "simds_occupied_frac": min(1.0, waves / 1024.0)}
+    if fsub:
+        flops = float(fsub["flops"]) * n_local * substeps
+        tf = flops / (kern_ms * 1e-3) / 1e12
+        out.update(achieved=tf, frac=tf / VALU_PEAK_TF, algorithmic_frac=tf / VALU_PEAK_TF, flops_per_launch=flops,
+                   flops_per_substep=fsub["flops"], op_counts=fsub, source=fsub_src)
+    st, src = committed("static_flops.json")
+    ent = (st or {}).get(cfg["env"]) or (st if st and cfg["env"] == "humanoidrun" and "valu_per_substep" in st else None)
+    if ent:
+        fl = ent["fp32_flops_per_lane_substep"] * 64.0 * waves * substeps
+        out["issued"] = {"flops_per_launch": fl, "achieved": fl / (kern_ms * 1e-3) / 1e12,
+                         "frac": fl / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TF,
+                         "valu_instr_per_wave_substep": ent["valu_per_substep"], "source": src}
+    return out
 
 
-def cpu_baseline(seconds_budget=15.0):
+def cpu_baseline(cfg, seconds_budget=15.0):
     """The oracle (a port, NOT the JAX reference — jax/brax are absent) timed on the host cores on a
-    bounded sample of the same workload: consecutive reverse-diffusion steps at N=1024, H=50."""
+    bounded sample of the same workload: consecutive reverse-diffusion steps of the config.  Also returns the
+    op counter's F_sub for the config's model (the oracle may only be touched from this leg)."""
     import numpy as np
     from oracle import oracle as orc_mod
     from oracle import planner as op
     from mbd_hip.model import Model
     orc_mod.build()
     orc = orc_mod.Oracle("f32_omp")
-    with open(os.path.join(ROOT, "model-based-diffusion_amd", "assets", "compiled", f"{ENV}.json")) as f:
-        m = Model.from_json(f.read())
-    env = op.OracleEnv(orc, ENV, m.to_struct(), init_q=m.init_q)
+    name, N, H, Nd, temp = cfg["env"], cfg["N"], cfg["H"], cfg["Nd"], cfg["temp"]
+    compiled = os.path.join(ROOT, "model-based-diffusion_amd", "assets", "compiled")
+    fsub = None
+    if name == "car2d":
+        env = op.OracleEnv(orc, "car2d", xref=np.load(os.path.join(compiled, "car2d_xref.npy")))
+    else:
+        with open(os.path.join(compiled, f"{name}.json")) as f:
+            m = Model.from_json(f.read())
+        xref = np.load(os.path.join(compiled, "jog_xref.npy")) if name == "humanoidtrack" else None
+        env = op.OracleEnv(orc, name, m.to_struct(), xref=xref, rew_xref=1.0 if xref is not None else 0.0,
+                           init_q=m.init_q)
+        ms = m.to_struct()
+        s = orc.forward(ms, m.init_q, np.zeros(m.qd_size(), np.float32))
+        a = np.full(m.act_size(), 0.3, np.float32)
+        for _ in range(12):  # the protocol of tools/count_ops.py: a state with the feet on the ground
+            s, _ = orc.env_step(ms, s, a)
+        fsub, _ = orc_mod.count_substep(ms, s, a)
     key = orc.prng_key(0)
     rng, rng_reset = orc.split(key, 2, 1)
     state0 = env.reset(rng_reset, 1)
-    sched = orc.schedule(1e-4, 1e-2, ND)
+    sched = orc.schedule(1e-4, 1e-2, Nd)
     Ybar = np.zeros((H, env.Nu), np.float32)
     r = orc.split(rng, 2, 1)[0]
     steps, t0 = 0, time.time()
-    i = ND - 1
+    i = Nd - 1
     while True:
-        r, Ybar, _, _ = op.reverse_once(orc, env, state0, i, r, Ybar, sched, N_PER_GPU, H, TEMP, 1)
+        r, Ybar, _, _ = op.reverse_once(orc, env, state0, i, r, Ybar, sched, N, H, temp, 1, enable_demo=cfg["demo"])
         steps += 1
         i -= 1
-        if time.time() - t0 > seconds_budget or i < 1:  # 10-15 s of host work, at most one whole plan (99 steps)
+        if time.time() - t0 > seconds_budget or i < 1:  # 10-15 s of host work, at most one whole plan
             break
     dt = time.time() - t0
     cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     return {"value": steps / dt, "unit": "diffusion-steps/sec", "cores": cores, "kind": "port",
-            "sample": f"{steps} consecutive reverse-diffusion steps of {ENV} N={N_PER_GPU} H={H} "
-                      f"(CPU oracle, OpenMP over candidates, {dt:.1f} s)"}
+            "sample": f"{steps} consecutive reverse-diffusion steps of {name} N={N} H={H} "
+                      f"(CPU oracle, OpenMP over candidates, {dt:.1f} s)"}, fsub
 
 
 def main():
@@ -108,9 +177,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="metric")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-final-reward", action="store_true")
     args = ap.parse_args()
+    cfg = CONFIGS[args.config]
+    ENV, N_CFG, H, ND, TEMP, DEMO = cfg["env"], cfg["N"], cfg["H"], cfg["Nd"], cfg["temp"], cfg["demo"]
+    if os.environ.get("MBD_BENCH_N"):  # experiments only
+        N_CFG = int(os.environ["MBD_BENCH_N"])
 
     # before the HIP runtime initialises: the host driver only supports dmabuf IPC (RCCL peer mappings)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -144,112 +219,157 @@ def main():
     from mbd_hip.planners.mbd_planner import Args, Plan, run_diffusion
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    N_total = N_PER_GPU * world
-    pargs = Args(seed=0, env_name=ENV, Nsample=N_total, Hsample=H, Ndiffuse=ND, temp_sample=TEMP,
-                 disable_recommended_params=True, not_render=True)
     env = get_env(ENV, device=local_rank)
-    key = _capi.prng_key(pargs.seed)
-    rng, rng_reset = _capi.prng_split(key, 2)
-    state_init = env.reset(rng_reset)
-    rng_exp, _ = _capi.prng_split(rng, 2)
-    plan = Plan(env, pargs, shard_begin=rank * N_PER_GPU, shard_count=N_PER_GPU)
-    plan.set_state0(state_init)
     Nu, HNu = env.action_size, H * env.action_size
-    lib, stream = plan.lib, torch.cuda.current_stream(dev).cuda_stream
+    n_frames = 1 if ENV == "car2d" else int(env.sys.fields["n_frames"])
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    rows = 2 if DEMO else 1
 
-    Ybar = torch.zeros(HNu, dtype=torch.float32, device=dev)
-    Ynext = torch.zeros(HNu, dtype=torch.float32, device=dev)
-    local = torch.zeros(N_PER_GPU, dtype=torch.float32, device=dev)
-    allv = torch.zeros(N_total, dtype=torch.float32, device=dev)
-    rew_mean = torch.zeros(1, dtype=torch.float32, device=dev)
-    state = {"rng": np.asarray(rng_exp, np.uint32), "i": ND - 1}
+    def measure(N_total, N_local):
+        """K synced + K async steps of a plan with N_total candidates of which this rank owns N_local."""
+        pargs = Args(seed=0, env_name=ENV, Nsample=N_total, Hsample=H, Ndiffuse=ND, temp_sample=TEMP,
+                     enable_demo=DEMO, disable_recommended_params=True, not_render=True)
+        key = _capi.prng_key(pargs.seed)
+        rng, rng_reset = _capi.prng_split(key, 2)
+        state_init = env.reset(rng_reset)
+        rng_exp, _ = _capi.prng_split(rng, 2)
+        plan = Plan(env, pargs, shard_begin=rank * N_local, shard_count=N_local)
+        plan.set_state0(state_init)
+        lib = plan.lib
+        Ybar = torch.zeros(HNu, dtype=torch.float32, device=dev)
+        Ynext = torch.zeros(HNu, dtype=torch.float32, device=dev)
+        local = torch.zeros((rows, N_local), dtype=torch.float32, device=dev)
+        allv = torch.zeros((rows, N_total), dtype=torch.float32, device=dev)
+        gath = torch.zeros((max(world, 1) * rows, N_local), dtype=torch.float32, device=dev)
+        rew_mean = torch.zeros(1, dtype=torch.float32, device=dev)
+        st = {"rng": np.asarray(rng_exp, np.uint32), "i": ND - 1, "Ybar": Ybar, "Ynext": Ynext}
 
-    def step():
-        nonlocal Ybar, Ynext
-        if state["i"] < 1:  # start the next plan: YN = zeros, fresh schedule position
-            state["i"] = ND - 1
-            Ybar.zero_()
-        keys = _capi.prng_split(state["rng"], 2)
-        state["rng"], ks = keys[0], _capi.key_array(keys[1])
-        i = state["i"]
-        _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Ybar.data_ptr(), local.data_ptr(), None, stream))
-        if distributed and backend == "nccl":
-            dist.all_gather_into_tensor(allv, local)  # the ONE collective of a diffusion step (RCCL/xGMI)
-            src = allv
-        elif distributed:  # gloo dry run: stage through the host
-            host = torch.empty(N_total, dtype=torch.float32)
-            dist.all_gather_into_tensor(host, local.cpu())
-            allv.copy_(host)
-            src = allv
-        else:
-            src = local
-        _capi.check(lib.mbd_plan_score_update(plan.h, i, ks, Ybar.data_ptr(), src.data_ptr(), None,
-                                              Ynext.data_ptr(), rew_mean.data_ptr(), stream))
-        Ybar, Ynext = Ynext, Ybar
-        state["i"] = i - 1
+        def step(read_back):
+            if st["i"] < 1:  # start the next plan: YN = zeros, fresh schedule position
+                st["i"] = ND - 1
+                st["Ybar"].zero_()
+            keys = _capi.prng_split(st["rng"], 2)
+            st["rng"], ks = keys[0], _capi.key_array(keys[1])
+            i, Yb = st["i"], st["Ybar"]
+            _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Yb.data_ptr(), local[0].data_ptr(),
+                                                    local[1].data_ptr() if DEMO else None, stream))
+            if distributed and backend == "nccl":
+                dist.all_gather_into_tensor(gath, local)  # the ONE collective of a diffusion step (RCCL/xGMI)
+                src = gath.view(world, rows, N_local).permute(1, 0, 2).reshape(rows, N_total) if rows > 1 else \
+                    gath.view(1, N_total)
+                src = src.contiguous() if rows > 1 else src
+            elif distributed:  # gloo dry run: stage through the host
+                host = torch.empty((world * rows, N_local), dtype=torch.float32)
+                dist.all_gather_into_tensor(host, local.cpu())
+                allv.copy_(host.view(world, rows, N_local).permute(1, 0, 2).reshape(rows, N_total))
+                src = allv
+            else:
+                src = local
+            _capi.check(lib.mbd_plan_score_update(plan.h, i, ks, Yb.data_ptr(), src[0].data_ptr(),
+                                                  src[1].data_ptr() if DEMO else None, st["Ynext"].data_ptr(),
+                                                  rew_mean.data_ptr(), stream))
+            st["Ybar"], st["Ynext"] = st["Ynext"], st["Ybar"]
+            st["i"] = i - 1
+            if read_back:  # pbar.set_postfix({"rew": f"{rew:.2e}"}) (mbd_planner.py:147): a device->host read per step
+                return float(rew_mean.item())
+            return None
 
-    def fence():
-        if distributed:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
+        def fence():
+            if distributed:
+                dist.barrier()
+            torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    plan.enable_timing(True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    plan.enable_timing(False)
-    kern_ms, kern_n = plan.kernel_time()
-    if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        def timed(read_back):
+            for _ in range(args.warmup):
+                step(read_back)
+            fence()
+            plan.enable_timing(True)
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step(read_back)
+            fence()
+            elapsed = time.perf_counter() - t0
+            plan.enable_timing(False)
+            kern_ms, kern_n = plan.kernel_time()
+            if distributed:
+                t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            return elapsed, kern_ms, kern_n
+
+        sync = timed(True)
+        asyn = timed(False)
+        plan.close()
+        return sync, asyn
+
+    strong_local = max(1, N_CFG // world)
+    runs = {"strong": (strong_local * world, strong_local)}
+    if world > 1:
+        runs["weak"] = (N_CFG * world, N_CFG)
+    res = {k: measure(*v) for k, v in runs.items() if k == args.scaling or world > 1}
+    if args.scaling not in res:  # one GPU, --scaling weak: the same measurement
+        res[args.scaling] = res["strong"]
 
     final = None
     if rank == 0 and not args.no_final_reward and not distributed:
         # the metric's second half: final reward of complete plans, seeds 0..7 as mbd/scripts/run_mbd.py:20
         rews = []
         for seed in range(8):
-            a = Args(seed=seed, env_name=ENV, Nsample=N_PER_GPU, Hsample=H, Ndiffuse=ND, temp_sample=TEMP,
-                     disable_recommended_params=True, not_render=True)
+            a = Args(seed=seed, env_name=ENV, Nsample=N_CFG, Hsample=H, Ndiffuse=ND, temp_sample=TEMP,
+                     enable_demo=DEMO, disable_recommended_params=True, not_render=True)
             with contextlib.redirect_stdout(sys.stderr):  # the reference prints "init sigma = ..." (:92); stdout
                 rews.append(float(run_diffusion(a, device=local_rank)))  # carries the one JSON line only
         final = {"seeds": list(range(8)), "rew_final": rews, "mean": float(np.mean(rews)),
                  "std": float(np.std(rews))}
-    plan.close()
 
     if rank == 0:
-        steps_per_sec = args.steps / elapsed
-        value = steps_per_sec * (N_total / N_PER_GPU)
-        balg = b_alg_bytes(N_PER_GPU, H, Nu)
+        def rate(mode, which):
+            (el_s, _, _), (el_a, _, _) = res[mode]
+            el = el_s if which == "sync" else el_a
+            N_total, _ = runs.get(mode, runs["strong"])
+            return (args.steps / el) * (N_total / N_CFG if mode == "weak" else 1.0), 1e3 * el / args.steps
+
+        mode = args.scaling
+        (el_s, kern_ms, kern_n), (el_a, kern_ms_a, _) = res[mode]
+        N_total, N_local = runs.get(mode, runs["strong"])
+        value, ms_sync = rate(mode, "sync")
+        value_async, ms_async = rate(mode, "async")
+        balg = b_alg_bytes(N_local, H, Nu, DEMO)
         achieved = (balg / 1e9) / (kern_ms / 1e3) if kern_ms > 0 else 0.0
-        traffic, traffic_src = pmc_traffic()
+        traffic, traffic_src = pmc_traffic(args.config)
         out = {
             "metric": "diffusion-steps/sec (N=1024, H=50) + final reward, humanoidrun, 1/2/4/8 GPU",
-            "value": value, "unit": "diffusion-steps/sec (1024-candidate steps, whole job)",
+            "value": value, "unit": "diffusion-steps/sec (whole job, per-step host read of the mean reward included)",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": ms_sync, "higher_is_better": True, "scaling": mode,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "steps_per_sec": steps_per_sec,
-            "config": {"workload": f"{ENV} N={N_PER_GPU}/GPU (N_total={N_total}) H={H} Ndiffuse={ND} "
-                                   f"temp={TEMP} seed=0 disable_recommended_params",
-                       "N_total": N_total, "N_per_gpu": N_PER_GPU, "H": H, "Nu": Nu,
-                       "collective": "all_gather(rews) per step" if distributed else "none"},
+            "value_async": value_async, "ms_per_step_async": ms_async,
+            "config": {"workload": f"{args.config}: {ENV} N_total={N_total} ({N_local}/GPU) H={H} Ndiffuse={ND} "
+                                   f"temp={TEMP}{' enable_demo' if DEMO else ''} seed=0 disable_recommended_params",
+                       "name": args.config, "N_total": N_total, "N_per_gpu": N_local, "H": H, "Nu": Nu,
+                       "n_frames": n_frames,
+                       "collective": "all_gather(rews) per step (variant B: every rank re-derives the softmax and the "
+                                     "weighted mean over all N from identical inputs)" if distributed else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "rollout_kernel<16,iso,noslide,3,1,dpp(1,-4,-6)>", "kernel_avg_ms": kern_ms,
+                         "kernel": cfg["kernel"], "kernel_avg_ms": kern_ms,
                          "kernel_launches": kern_n, "algorithmic_bytes_per_launch": balg,
                          "note": "state stays in VGPRs for all H*n_frames substeps: the kernel is bound by "
                                  "dependent FP32 VALU issue, not HBM (DESIGN.md §Roofline)"},
-            "valu": valu_view(kern_ms, N_PER_GPU // 4, H * 7),
             "final_reward": final,
         }
+        if world > 1:
+            other = "weak" if mode == "strong" else "strong"
+            ov, oms = rate(other, "sync")
+            oa, _ = rate(other, "async")
+            out["other_scaling"] = {"scaling": other, "value": ov, "ms_per_step": oms, "value_async": oa,
+                                    "N_total": runs[other][0], "N_per_gpu": runs[other][1]}
+        fsub, fsub_src = op_counts(ENV)
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"], live = cpu_baseline(cfg)
+            if live:
+                fsub, fsub_src = live, "oracle/count_ops.cc (this run)"
+        out["valu"] = valu_view(cfg, N_local, kern_ms, n_frames, fsub, fsub_src)
         print(json.dumps(out))
     if distributed:
         dist.barrier()

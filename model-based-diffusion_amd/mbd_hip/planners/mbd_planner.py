@@ -150,21 +150,33 @@ def shard_bounds(N: int, world: int, rank: int):
 def exchange_rewards(local, world: int, group=None):
     """The ONE exchange step of a diffusion step: every rank contributes the per-candidate values of its
     shard (``local`` [rows, shard]) and receives all N of them, rank-major = candidate order, as
-    [rows, N].  One all-gather (RCCL over xGMI on GPUs, gloo in the CPU tests)."""
+    [rows, N].  One all-gather (RCCL over xGMI on GPUs; gloo in the CPU tests and in the two-ranks-on-one-GPU
+    dry runs, where device tensors are staged through the host)."""
     import torch
     import torch.distributed as dist
     if world == 1:
         return local
     rows, sh = local.shape
-    gathered = torch.empty((world * rows, sh), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)  # concatenation along dim 0
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        host = torch.empty((world * rows, sh), dtype=local.dtype)
+        dist.all_gather_into_tensor(host, local.detach().cpu().contiguous(), group=group)
+        gathered = host.to(local.device)
+    else:
+        gathered = torch.empty((world * rows, sh), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(gathered, local.contiguous(), group=group)  # concatenation along dim 0
     return gathered.view(world, rows, sh).permute(1, 0, 2).reshape(rows, world * sh).contiguous()
 
 
-def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bool = False):
+def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bool = False, progress=None,
+                        phase_times: dict = None):
     """reverse() (mbd_planner.py:138-148) with the candidates sharded over the ranks of ``group``.
     One all-gather of the per-candidate mean rewards per diffusion step (plus the demo log-densities
-    when enabled, packed in the same buffer). Returns (mu_0ts, rew_means) as CUDA tensors."""
+    when enabled, packed in the same buffer). Returns (mu_0ts, rew_means) as CUDA tensors.
+
+    ``sync_every_step`` / ``progress``: the reference formats the step's mean reward for its progress bar every
+    step (:147), which is a device->host read per step; ``progress(i, rew)`` receives that value.
+    ``phase_times``: a dict that receives HIP-event milliseconds per step of phase 1 (sample + rollout), the
+    exchange and phase 2 (score + weighted mean) — each phase is then fenced, for measurement only."""
     import torch
     import torch.distributed as dist
 
@@ -182,29 +194,51 @@ def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bo
     rng = np.asarray(key, np.uint32)
     impl = plan.cfg.prng_impl
     lib = plan.lib
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if phase_times is not None else None
+    acc = [0.0, 0.0, 0.0]
     for i in range(plan.Nd - 1, 0, -1):
         keys = _capi.prng_split(rng, 2, impl)  # rng, Y0s_rng = split(rng)  (mbd_planner.py:103)
         rng, ks = keys[0], _capi.key_array(keys[1])
+        if ev:
+            ev[0].record()
         _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Ybar.data_ptr(), local[0].data_ptr(),
                                                 local[1].data_ptr() if demo else None, stream))
+        if ev:
+            ev[1].record()
         allv = exchange_rewards(local, world, group)
+        if ev:
+            ev[2].record()
         out = mu[plan.Nd - 1 - i]
         _capi.check(lib.mbd_plan_score_update(plan.h, i, ks, Ybar.data_ptr(), allv[0].data_ptr(),
                                               allv[1].data_ptr() if demo else None, out.data_ptr(),
                                               rew_means[plan.Nd - 1 - i:].data_ptr(), stream))
         Ybar = out
-        if sync_every_step:  # the reference formats the reward every step (mbd_planner.py:147)
-            float(rew_means[plan.Nd - 1 - i])
+        if ev:
+            ev[3].record()
+            ev[3].synchronize()
+            for k in range(3):
+                acc[k] += ev[k].elapsed_time(ev[k + 1])
+        if sync_every_step or progress is not None:  # the reference formats the reward every step (:147)
+            r = float(rew_means[plan.Nd - 1 - i])
+            if progress is not None:
+                progress(i, r)
+    if phase_times is not None:
+        n = max(plan.Nd - 1, 1)
+        phase_times.update(phase1_ms=acc[0] / n, exchange_ms=acc[1] / n, phase2_ms=acc[2] / n, steps=plan.Nd - 1)
     return mu.view(plan.Nd - 1, plan.H, plan.Nu), rew_means
 
 
-def run_diffusion(args: Args, device: int = None, return_details: bool = False):
+def run_diffusion(args: Args, device: int = None, return_details: bool = False, progress=None,
+                  force_single: bool = False, measure_phases: bool = False):
     """mbd_planner.py:38-182. Returns rew_final (float); ``return_details`` adds a dict with mu_0ts,
-    per-step mean rewards and the reverse-loop wall time."""
+    per-step mean rewards and the reverse-loop wall time.  ``progress(i, rew)`` is called after every diffusion
+    step with the step's mean reward, like the reference's progress bar (:147) — one device->host read per step;
+    without it the loop runs asynchronously and the means are read once at the end.  ``force_single`` ignores an
+    initialised process group (every rank then runs the whole plan)."""
     import torch
     import torch.distributed as dist
 
-    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    distributed = (not force_single) and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
     if device is None:
         device = int(os.environ.get("LOCAL_RANK", "0")) if distributed else 0
     rng = _capi.prng_key(args.seed)  # :40
@@ -224,11 +258,12 @@ def run_diffusion(args: Args, device: int = None, return_details: bool = False):
     _, _, sigmas = plan.schedule()
     print(f"init sigma = {sigmas[-1]:.2e}")  # :93
 
-    if distributed:
+    phases = {} if measure_phases else None
+    if distributed or progress is not None or measure_phases:
         torch.cuda.set_device(device)
         torch.cuda.synchronize(device)
         t0 = time.time()
-        mu_t, rm_t = reverse_distributed(plan, rng_exp, device)
+        mu_t, rm_t = reverse_distributed(plan, rng_exp, device, progress=progress, phase_times=phases)
         torch.cuda.synchronize(device)
         secs = time.time() - t0
         mu, rew_means = mu_t.cpu().numpy(), rm_t.cpu().numpy()
@@ -246,7 +281,8 @@ def run_diffusion(args: Args, device: int = None, return_details: bool = False):
     plan.close()
     if return_details:
         return rew_final, dict(mu_0ts=mu, rew_means=rew_means, loop_seconds=secs, state_init=state_init,
-                               steps_per_sec=(args.Ndiffuse - 1) / secs)
+                               steps_per_sec=(args.Ndiffuse - 1) / secs, sharded=bool(distributed),
+                               world=dist.get_world_size() if distributed else 1, phase_ms=phases)
     return rew_final
 
 
@@ -260,5 +296,6 @@ if __name__ == "__main__":
         else:
             p.add_argument(f"--{f.name}", type=type(f.default), default=f.default)
     ns = p.parse_args()
-    rew_final = run_diffusion(Args(**vars(ns)))
-    print(f"final reward = {rew_final:.2e}")  # :187
+    rew_final = run_diffusion(Args(**vars(ns)), progress=lambda i, rew: print(f"\rDiffusing i={i:4d} rew {rew:.2e}",
+                                                                                 end="", flush=True))  # :141-147
+    print(f"\nfinal reward = {rew_final:.2e}")  # :187

@@ -22,8 +22,8 @@ LINK_STATE = 13
 
 def build(force: bool = False) -> None:
     """Compile the oracle with gcc (seconds). Building the checker is not using it."""
-    libs = ["liboracle_f32.so", "liboracle_f64.so", "liboracle_f32_omp.so"]
-    srcs = [os.path.join(_HERE, s) for s in ("mbd_oracle_core.c", "mbd_oracle_physics.c")]
+    libs = ["liboracle_f32.so", "liboracle_f64.so", "liboracle_f32_omp.so", "liboracle_count.so"]
+    srcs = [os.path.join(_HERE, s) for s in ("mbd_oracle_core.c", "mbd_oracle_physics.c", "spec_math.h", "count_ops.cc")]
     srcs.append(os.path.join(_HERE, "..", "include", "mbd_hip.h"))
     newest = max(os.path.getmtime(s) for s in srcs)
     stale = force or any(
@@ -31,6 +31,20 @@ def build(force: bool = False) -> None:
         for l in libs)
     if stale:
         subprocess.run(["make", "-s", "-C", _HERE, "all"], check=True)
+
+
+def count_substep(model_struct, state, action):
+    """Op counts of ONE physics substep as executed by the restatement (oracle/count_ops.cc): a dict with
+    add, mul, fma, div, sqrt, cmp and flops = add + mul + 2 fma + div + sqrt (F_sub(model))."""
+    build()
+    lib = C.CDLL(os.path.join(_BUILD, "liboracle_count.so"))
+    lib.orc_count_substep.argtypes = [C.c_void_p, _f32p, _f32p, _f32p, np.ctypeslib.ndpointer(np.uint64)]
+    st = np.ascontiguousarray(state, np.float32).reshape(-1)
+    out, cnt = np.zeros_like(st), np.zeros(6, np.uint64)
+    lib.orc_count_substep(C.addressof(model_struct), st, np.ascontiguousarray(action, np.float32), out, cnt)
+    d = dict(zip(("add", "mul", "fma", "div", "sqrt", "cmp"), (int(x) for x in cnt)))
+    d["flops"] = d["add"] + d["mul"] + 2 * d["fma"] + d["div"] + d["sqrt"]
+    return d, out
 
 
 class Oracle:

@@ -14,39 +14,52 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-KERNEL = "_ZN3mbd14rollout_kernelILi16ELb1ELb0ELi3ELi1ELi1ELin4ELin6ELi0EEEvNS_13RolloutParamsE"
+# env -> template arguments of the instantiation launch_rollout() picks for it (csrc/mbd_capi.hip)
+INSTANCES = {
+    "humanoidrun": "16,true,false,3,1,1,-4,-6,0,false,true",
+    "humanoidtrack": "16,true,false,3,1,1,-4,-6,0,false,true",
+    "humanoidstandup": "16,true,false,3,5,1,-4,-6,0,false,true",
+    "ant": "16,true,false,4,2,1,-2,-4,-6,false,false",
+    "halfcheetah": "8,true,true,4,2,1,-3,0,0,false,false",
+    "walker2d": "8,false,true,4,2,1,-3,0,0,true,false",
+    "hopper": "4,false,true,4,2,1,0,0,0,true,false",
+    "cartpole": "4,true,true,4,2,1,0,0,0,false,false",
+}
 
 
-def main():
+def count(targs):
     csrc = os.path.join(ROOT, "model-based-diffusion_amd", "csrc")
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "k.hip")
         with open(src, "w") as f:
-            f.write(f'#include "{csrc}/mbd_kernels.h"\ntemplate __global__ void mbd::rollout_kernel<16,true,false,3,1,1,-4,-6>(mbd::RolloutParams);\n')
+            f.write(f'#include "{csrc}/mbd_kernels.h"\ntemplate __global__ void mbd::rollout_kernel<{targs}>(mbd::RolloutParams);\n')
         out = os.path.join(td, "k.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                         "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-S", "--cuda-device-only", src,
                         "-o", out], check=True, capture_output=True)
         body = open(out).read().split("\n")
-    start = [i for i, l in enumerate(body) if l.startswith(KERNEL + ":")][0]
+    start = [i for i, l in enumerate(body) if re.match(r"^_ZN3mbd14rollout_kernel.*:", l)][0]
     end = [i for i, l in enumerate(body) if i > start and ".Lfunc_end" in l][0]
+    meta = "\n".join(body[end:])
     body = body[start:end]
     lab = {}
     for k, l in enumerate(body):
         m = re.match(r"^(\.LBB\d+_\d+):", l)
         if m:
             lab[m.group(1)] = k
-    loops = []
+    loops = []  # (first line, last line, instructions) of every backward branch
     for k, l in enumerate(body):
         m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
         if m and m.group(1) in lab and lab[m.group(1)] < k:
             ins = [x.strip().split()[0] for x in body[lab[m.group(1)]:k + 1]
                    if x.startswith("\t") and x.strip() and not x.strip().startswith((".", ";"))]
-            loops.append((sum(1 for i in ins if i.startswith("ds_")), sum(1 for i in ins if "dpp" in i), ins))
-    # the substep loop = the smallest loop holding one substep's DPP row shifts (57 of them: the parent<->child
-    # traffic); the control-step loop around it holds them too, but is longer.  (The compiler may rotate a few of
-    # the 13 prefetching ds_bpermute of a substep into the loop's entry block, so they are not a reliable marker.)
-    best = min((ins for n, d, ins in loops if d >= 50), key=len)
+            loops.append((lab[m.group(1)], k, ins))
+    # the longest backward-branch region is the control-step loop (over H); the substep loop (over n_frames) is the
+    # longest region strictly inside it (the other backward branches in there are out-of-line slow paths — the exact
+    # square root of the quaternion renormalisation — jumping back into the loop, and the small gather loops)
+    outer = max(loops, key=lambda t: len(t[2]))
+    inner = [t for t in loops if t[0] > outer[0] and t[1] < outer[1] and len(t[2]) <= len(outer[2]) - 100]
+    best = max(inner, key=lambda t: len(t[2]))[2]
     c = collections.Counter(best)
     flops = 0
     for k, v in c.items():
@@ -58,15 +71,32 @@ def main():
             flops += 2 * v
         elif k.startswith(("v_mul_f32", "v_add_f32", "v_sub_f32", "v_rcp_f32", "v_sqrt_f32", "v_div_")):
             flops += v
-    res = {"instructions_per_substep": len(best), "valu_per_substep": sum(v for k, v in c.items() if k.startswith("v_")),
-           "lds_instr_per_substep": sum(v for k, v in c.items() if k.startswith("ds_")), "fp32_flops_per_lane_substep": flops}
-    print(json.dumps(res))
-    if "--hist" in sys.argv:
-        for k, v in c.most_common():
-            print(f"{v:5d} {k}")
+    vg = re.search(r"; NumVgprs:\s+(\d+)", meta)
+    sc = re.search(r"; ScratchSize:\s+(\d+)", meta)
+    res = {"template_args": targs, "instructions_per_substep": len(best),
+           "valu_per_substep": sum(v for k, v in c.items() if k.startswith("v_")),
+           "lds_instr_per_substep": sum(v for k, v in c.items() if k.startswith("ds_")),
+           "dpp_per_substep": sum(v for k, v in c.items() if "dpp" in k),
+           "s_nop_per_substep": c.get("s_nop", 0), "s_waitcnt_per_substep": c.get("s_waitcnt", 0),
+           "fp32_flops_per_lane_substep": flops, "vgpr": int(vg.group(1)) if vg else None,
+           "scratch_bytes": int(sc.group(1)) if sc else None}
+    return res, c
+
+
+def main():
+    tag = next((a for a in sys.argv[1:] if a.startswith("r") and a[1:].isdigit()), "r02")
+    envs = [a for a in sys.argv[1:] if a in INSTANCES] or list(INSTANCES)
+    out = {}
+    for env in envs:
+        res, c = count(INSTANCES[env])
+        out[env] = res
+        print(env, json.dumps(res))
+        if "--hist" in sys.argv:
+            for k, v in c.most_common():
+                print(f"{v:5d} {k}")
     if "--write" in sys.argv:
-        with open(os.path.join(ROOT, "profiles", "r01_static_flops.json"), "w") as f:
-            json.dump(res, f, indent=1)
+        with open(os.path.join(ROOT, "profiles", f"{tag}_static_flops.json"), "w") as f:
+            json.dump(out, f, indent=1)
 
 
 if __name__ == "__main__":

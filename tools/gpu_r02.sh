@@ -1,0 +1,30 @@
+#!/bin/bash
+# round-2 measurement pass: tests, bench line per single-GPU config, rocprofv3 kernel stats + PMC passes per config
+# usage (on the GPU box): tools/gpu_r02.sh [tests] [bench] [prof CONFIG...]
+cd "$GRAFT_REPO_ROOT" || exit 1
+R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT
+python __graft_entry__.py 2>&1 | tail -1
+what="$*"; [ -z "$what" ] && what="tests bench prof metric hopper512 halfcheetah1024"
+if [[ " $what " == *" tests "* ]]; then
+  timeout 1200 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 | tee $OUT/pytest_r02.log
+fi
+if [[ " $what " == *" bench "* ]]; then
+  python bench.py --steps 60 --warmup 10 2>$OUT/bench_err.log | tail -1 > $OUT/bench_r02_metric.json; cat $OUT/bench_r02_metric.json
+  for c in hopper512 halfcheetah1024 humanoidrun4096 humanoidtrack2048demo car2d; do
+    python bench.py --config $c --steps 40 --warmup 5 2>>$OUT/bench_err.log | tail -1 > $OUT/bench_r02_$c.json; cat $OUT/bench_r02_$c.json
+  done
+fi
+if [[ " $what " == *" prof "* ]]; then
+  cd /tmp && export TMPDIR=/tmp
+  for c in metric hopper512 halfcheetah1024 humanoidrun4096 humanoidtrack2048demo; do
+    [[ " $what " == *" $c "* ]] || continue
+    B="python $R/bench.py --config $c --no-cpu-baseline --no-final-reward"
+    rocprofv3 --kernel-trace --stats -d $OUT/prof_${c}_stats -o r02 -- $B --steps 60 --warmup 10 > $OUT/prof_${c}_stats.log 2>&1
+    rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY --kernel-trace -d $OUT/prof_${c}_sq -o r02 -- $B --steps 20 --warmup 2 > $OUT/prof_${c}_sq.log 2>&1
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_${c}_fetch -o r02 -- $B --steps 20 --warmup 2 > $OUT/prof_${c}_fetch.log 2>&1
+    rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-trace -d $OUT/prof_${c}_write -o r02 -- $B --steps 20 --warmup 2 > $OUT/prof_${c}_write.log 2>&1
+    rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC --kernel-trace -d $OUT/prof_${c}_wait -o r02 -- $B --steps 20 --warmup 2 > $OUT/prof_${c}_wait.log 2>&1
+  done
+  find $OUT -name "*.db" | head -40
+fi
+du -sh $OUT

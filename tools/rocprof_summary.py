@@ -1,7 +1,8 @@
 """Summarise rocprofv3 (rocpd sqlite) outputs under gpurun_out/ into small tracked files in profiles/.
 
-usage: python tools/rocprof_summary.py <round-tag> <stats_db> [<pmc_db> ...]
-Writes profiles/<tag>_kernel_stats.md and profiles/<tag>_pmc.json (per-kernel averages per launch).
+usage: python tools/rocprof_summary.py <round-tag> [--config NAME] <stats_db> [<pmc_db> ...]
+Writes profiles/<tag>_kernel_stats[_NAME].md and merges the per-kernel counter averages per launch into
+profiles/<tag>_pmc.json under the key NAME (the bench config the profiled command ran; default "metric").
 HBM bytes follow MI355X_MICROARCH.md §HBM: FETCH_SIZE / WRITE_SIZE are in KiB and on gfx950
 FETCH_SIZE reports half of a wide coalesced read stream (doubled here; the raw value is kept too).
 """
@@ -12,14 +13,20 @@ import sys
 
 
 def main():
-    tag, stats_db, pmc_dbs = sys.argv[1], sys.argv[2], sys.argv[3:]
+    argv = sys.argv[1:]
+    config = "metric"
+    if "--config" in argv:
+        k = argv.index("--config")
+        config = argv[k + 1]
+        del argv[k:k + 2]
+    tag, stats_db, pmc_dbs = argv[0], argv[1], argv[2:]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out_dir = os.path.join(root, "profiles")
     os.makedirs(out_dir, exist_ok=True)
     con = sqlite3.connect(stats_db)
     rows = list(con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
     lines = [f"# rocprofv3 --kernel-trace --stats ({tag})", "",
-             "command: `rocprofv3 --kernel-trace --stats -- python bench.py --steps 60 --warmup 10 "
+             f"command: `rocprofv3 --kernel-trace --stats -- python bench.py --config {config} --steps 60 --warmup 10 "
              "--no-cpu-baseline --no-final-reward` (durations in microseconds)", "",
              "| kernel | calls | total_us | avg_us | % |", "|---|---:|---:|---:|---:|"]
     for name, calls, tot, avg, pct in rows:
@@ -30,7 +37,8 @@ def main():
               "|---|---:|---:|---:|---:|---:|---:|---:|---:|"]
     for r in kinfo:
         lines.append("| `" + str(r[0])[:80] + "` | " + " | ".join(str(x) for x in r[1:]) + " |")
-    with open(os.path.join(out_dir, f"{tag}_kernel_stats.md"), "w") as f:
+    suffix = "" if config == "metric" else f"_{config}"
+    with open(os.path.join(out_dir, f"{tag}_kernel_stats{suffix}.md"), "w") as f:
         f.write("\n".join(lines) + "\n")
     pmc = {}
     for db in pmc_dbs:
@@ -43,8 +51,15 @@ def main():
             f_kib, w_kib = d["FETCH_SIZE"]["avg_per_launch"], d["WRITE_SIZE"]["avg_per_launch"]
             d["hbm_bytes_per_launch_corrected"] = (2.0 * f_kib + w_kib) * 1024.0
             d["hbm_bytes_per_launch_raw"] = (f_kib + w_kib) * 1024.0
-    with open(os.path.join(out_dir, f"{tag}_pmc.json"), "w") as f:
-        json.dump(pmc, f, indent=1, sort_keys=True)
+    path = os.path.join(out_dir, f"{tag}_pmc.json")
+    merged = {}
+    if os.path.exists(path):
+        with open(path) as f:
+            merged = json.load(f)
+    if pmc:
+        merged[config] = pmc
+    with open(path, "w") as f:
+        json.dump(merged, f, indent=1, sort_keys=True)
     print("\n".join(lines[:14]))
     for k, d in pmc.items():
         if "rollout" in k:
