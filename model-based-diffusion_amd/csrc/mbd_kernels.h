@@ -38,6 +38,8 @@ struct RolloutParams {
   int slide_limits;  // any slide dof with a finite range (wave-uniform: the limit corrections are skipped otherwise)
   int max_children;  // largest child count in the model (wave-uniform bound of the generic kernels' child loops)
   int max_rot;       // largest number of hinge dofs on one joint (1: hopper, walker2d, halfcheetah, ant, cartpole)
+  int has_weld;      // some joint has no hinge dof (slide-only / weld: the cartpole's cart): wave-uniform, the orientation
+                     // lock of stage (3) is skipped otherwise (it would be discarded by its select)
   // DPP instantiations only: lane (within the 16-lane row) <-> link tables, [0..15] lane -> link (-1: padding),
   // [16..31] link -> lane.  Device memory, written by the host when the model's tree fits the shift pattern.
   const signed char* lane_tab;
@@ -365,6 +367,43 @@ __device__ __forceinline__ v3 iinv_z0(const Inert<ISO>& in, const WInert<ISO>& W
   }
 }
 
+// ---- two colliders of ONE link at once (stage (4) is a Jacobi solve: every contact sees the same pose): the same
+// primitives on (collider 0, collider 1) pairs, component-wise identical roundings
+__device__ __forceinline__ q4x2 bcast4(q4 q) { return q4x2{mk2(q.w, q.w), mk2(q.x, q.x), mk2(q.y, q.y), mk2(q.z, q.z)}; }
+__device__ __forceinline__ v3x2 irot_z2(f2 d, q4x2 q) {
+  f2 a = q.y * d, b = q.x * d;
+  f2 tx = -(a + a), ty = b + b;
+  f2 cx = q.z * ty, cy = -(q.z * tx), cz = fma2(-q.x, ty, q.y * tx);
+  return v3x2{fma2(q.w, tx, cx), fma2(q.w, ty, cy), d + cz};
+}
+template <bool ISO>
+__device__ __forceinline__ v3x2 iinv_s2(const Inert<ISO>& in, const WInert<ISO>& W, v3x2 v) {
+  if constexpr (ISO) {
+    return scale2(v, mk2(in.ib[0], in.ib[0]));
+  } else {
+    auto b = [&](int k) { return mk2(W.w[k], W.w[k]); };
+    v3x2 m;
+    m.x = fma2(b(4), v.z, fma2(b(3), v.y, b(0) * v.x));
+    m.y = fma2(b(5), v.z, fma2(b(1), v.y, b(3) * v.x));
+    m.z = fma2(b(2), v.z, fma2(b(5), v.y, b(4) * v.x));
+    return m;
+  }
+}
+template <bool ISO>
+__device__ __forceinline__ v3x2 iinv_z0_s2(const Inert<ISO>& in, const WInert<ISO>& W, v3x2 v) {
+  if constexpr (ISO) {
+    const f2 ib = mk2(in.ib[0], in.ib[0]);
+    return v3x2{v.x * ib, v.y * ib, mk2(0.0f, 0.0f)};
+  } else {
+    auto b = [&](int k) { return mk2(W.w[k], W.w[k]); };
+    return v3x2{fma2(b(3), v.y, b(0) * v.x), fma2(b(1), v.y, b(3) * v.x), fma2(b(5), v.y, b(4) * v.x)};
+  }
+}
+__device__ __forceinline__ f2 dot_az0_2(v3x2 a, v3x2 b) { return fma2(a.x, b.x, a.y * b.y); }
+__device__ __forceinline__ v3x2 cross_bz0_2(v3x2 a, v3x2 b) {
+  return v3x2{-(a.z * b.y), a.z * b.x, fma2(a.x, b.y, -(a.y * b.x))};
+}
+
 // LPS   lanes per candidate (power of two >= n_links)
 // ISO   model-wide isotropic inverse inertia (spring_inertia_scale = 1 models: the humanoid)
 // SLIDES any slide dof in the model (planar roots of hopper / halfcheetah)
@@ -372,8 +411,12 @@ __device__ __forceinline__ v3 iinv_z0(const Inert<ISO>& in, const WInert<ISO>& W
 // D0..D3: DPP layout, lane(parent) = lane(s-th child) + Ds (D0 = 0: off; a trailing 0: the model has no such
 // slot).  Groups of LPS lanes never straddle a 16-lane DPP row, and the 0/1 masks discard whatever a shift
 // pulls in from a neighbouring candidate of the same row.
+// NS    slide slots in use (the model's largest slide count, 1..3): the loops over slide dofs stop there
+// SLIDEW every joint with a slide dof hangs off the WORLD (planar roots, the cartpole's cart): its parent-side joint
+//       frame is the constant ap_rot (identity (x) ap_rot, up to the sign of zeros), so the world-frame slide axes
+//       rot(slide_axis, aprot) are per-lane constants instead of a rotation per slot, stage and substep
 template <int LPS, bool ISO, bool SLIDES, int MAXCH, int MAXCOL, int D0 = 0, int D1 = 0, int D2 = 0, int D3 = 0,
-          bool DIAG = false, bool MULTI = true>
+          bool DIAG = false, bool MULTI = true, int NS = 3, bool SLIDEW = false>
 __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
   constexpr bool DPP = D0 != 0;
   static_assert(!DPP || ((D1 != 0 || D2 == 0) && (D2 != 0 || D3 == 0) && (D3 == 0 || MAXCH >= 4)),
@@ -457,6 +500,10 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
     saxis[k] = sel3(has_sl, saxis[k], mk3(0.0f, 0.0f, 0.0f));
     gear_sl[k] = has_sl ? gear_sl[k] : 0.0f;
   }
+  v3 saxis_w[3];  // SLIDEW: the slide axes in the world frame, once
+#pragma unroll
+  for (int k = 0; k < 3; ++k) saxis_w[k] = rot(saxis[k], jc.ap_rot);
+  auto slide_dir = [&](int k, q4 aprot) { return SLIDEW ? saxis_w[k] : rot(saxis[k], aprot); };
   int child_lane[MAXCH];
   {
     int nc = 0;
@@ -617,8 +664,8 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         }
         if constexpr (SLIDES) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            v3 s = rot(saxis[k], f.aprot);
+          for (int k = 0; k < NS; ++k) {
+            v3 s = slide_dir(k, f.aprot);
             float vs = dot(rel_v, s);
             float fk = ffma(-sl_damp[k], vs, tau_sl[k]);  // motor + MJCF joint damping of the slide dof
             F = axpy(fk, s, F);  // (s = 0 for a slot the joint lacks)
@@ -688,8 +735,8 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         v3 d = sub(f.ap, f.ac);
         if constexpr (SLIDES) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            v3 s = rot(saxis[k], f.aprot);
+          for (int k = 0; k < NS; ++k) {
+            v3 s = slide_dir(k, f.aprot);
             float cf = -dot(d, s);
             d = axpy(cf, s, d);
           }
@@ -707,7 +754,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         const float dxy = dot(f.Xp, f.Yc);
         float sc = nr_eff == 1 ? 1.0f : (nr_eff == 2 ? dxy : 0.0f);
         v3 e = scale(cross(A, Bv), sc);
-        if constexpr (SLIDES) {  // joints without a hinge dof keep the child's orientation locked to the parent's
+        if (SLIDES && P.has_weld) {  // joints without a hinge dof keep the child's orientation locked to the parent's
           q4 qe = qmul(f.aprot, conj(f.acrot));
           float sg = qe.w < 0.0f ? -2.0f : 2.0f;
           e = sel3(nr_eff == 0, mk3(sg * qe.x, sg * qe.y, sg * qe.z), e);
@@ -762,8 +809,8 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         // slide (planar roots of hopper / walker2d / halfcheetah) skip the block: it would add exact zeros.
         if (SLIDES && P.slide_limits) {
 #pragma unroll
-          for (int k = 0; k < 3; ++k) {
-            v3 sx = rot(saxis[k], f.aprot);
+          for (int k = 0; k < NS; ++k) {
+            v3 sx = slide_dir(k, f.aprot);
             float qs = dot(sub(f.ac, f.ap), sx);
             float viol = qs - fclip(qs, sl_lo[k], sl_hi[k]);
             v3 dl = scale(sx, -viol);
@@ -845,6 +892,48 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
       {
         const WInert<ISO> Wc = world_inertia<ISO, DIAG>(ic, r);  // (r not yet renormalised, like the contact points)
         v3 cd_p = mk3(0, 0, 0), cd_th = mk3(0, 0, 0);
+        if constexpr (MAXCOL == 2) {
+          // both colliders of the link as one packed pair (the solve is Jacobi: each sees the pose of the stage's
+          // start); their corrections are then added in collider order, exactly like the loop below
+          const q4x2 R2 = bcast4(r);
+          const v3x2 cpos = pack3(col_pos[0], col_pos[1]);
+          const f2 rad = mk2(col_rad[0], col_rad[1]);
+          const v3x2 off = rot2(cpos, R2);
+          const v3x2 ctr = add2(bcast3(p), off);
+          const f2 pen = rad - ctr.z;
+          const bool act0 = col_has[0] && pen.x > 0.0f, act1 = col_has[1] && pen.y > 0.0f;
+          const f2 h = fma2(mk2(-0.5f, -0.5f), pen, rad);
+          const v3x2 pos = v3x2{ctr.x, ctr.y, ctr.z - h};
+          const v3x2 rc = v3x2{off.x, off.y, off.z - h};
+          const v3x2 cn = v3x2{rc.y, -rc.x, mk2(0.0f, 0.0f)};
+          const v3x2 icn = iinv_z0_s2<ISO>(ic, Wc, cn);
+          const f2 wn = mk2(ic.inv_mass, ic.inv_mass) + dot_az0_2(cn, icn);
+          const v3x2 rl = add2(cpos, irot_z2(-h, R2));
+          const v3x2 pprev = add2(bcast3(p_prev), rot2(rl, bcast4(r_prev)));
+          v3x2 dx = sub2(pos, pprev);
+          dx.z = mk2(0.0f, 0.0f);
+          const f2 ct2 = fma2(dx.x, dx.x, dx.y * dx.y);
+          const v3x2 cnt = cross_bz0_2(rc, dx);
+          const v3x2 icnt = iinv_s2<ISO>(ic, Wc, cnt);
+          const f2 dent = fma2(mk2(ic.inv_mass, ic.inv_mass), ct2, dot2(cnt, icnt));
+          f2 q_n, q_g;  // (dlam / collide_scale, gt) of both colliders
+          div2x2_(pen, wn, ct2, dent + mk2(1e-20f, 1e-20f), q_n, q_g);
+          const f2 dlam = q_n * mk2(coll_scale, coll_scale);
+          const f2 lim = mk2(mu, mu) * dlam;
+          const f2 lhs = (ct2 * q_g) * q_g, rhs = lim * lim;
+          const bool st0 = lhs.x < rhs.x, st1 = lhs.y < rhs.y;
+          const f2 px = (-q_g) * dx.x, py = (-q_g) * dx.y;
+          const v3x2 Pimp = v3x2{mk2(st0 ? px.x : 0.0f, st1 ? px.y : 0.0f), mk2(st0 ? py.x : 0.0f, st1 ? py.y : 0.0f), dlam};
+          const v3x2 dth = iinv_s2<ISO>(ic, Wc, cross2(rc, Pimp));
+          const v3 P0 = lo3(Pimp), P1 = hi3(Pimp), dth0 = lo3(dth), dth1 = hi3(dth);
+          cd_p = sel3(act0, scale(P0, ic.inv_mass), cd_p);
+          cd_th = sel3(act0, dth0, cd_th);
+          cd_p = sel3(act1, axpy(ic.inv_mass, P1, cd_p), cd_p);
+          cd_th = sel3(act1, add(cd_th, dth1), cd_th);
+          con_pos[0] = lo3(pos); con_pos[1] = hi3(pos);
+          con_dlam[0] = dlam.x; con_dlam[1] = dlam.y;
+          con_act[0] = act0; con_act[1] = act1;
+        } else {
 #pragma unroll
         for (int j = 0; j < MAXCOL; ++j) {
           const v3 off = rot(col_pos[j], r);
@@ -883,6 +972,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           cd_p = sel3(active, ncd_p, cd_p);
           cd_th = sel3(active, ncd_th, cd_th);
           con_pos[j] = pos; con_dlam[j] = dlam; con_act[j] = active;
+        }
         }
         p = add(p, cd_p);  // zero corrections on links without colliders
         r = qrotvec(r, cd_th);
@@ -938,7 +1028,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
       q4 Pr = shfl4(r, plane);
       if (world_parent) { Pp = mk3(0, 0, 0); Pr = q4{1, 0, 0, 0}; }
       JointFrames f = joint_frames(jc, Pp, Pr, p, r, multi);
-      v3 sx = rot(saxis[0], f.aprot);
+      v3 sx = slide_dir(0, f.aprot);
       v3 vc = add(v, cross(w, sub(f.ac, p)));  // link 0 hangs off the static world
       float sn, cs;
       sincos_(f.ang0, &sn, &cs);
