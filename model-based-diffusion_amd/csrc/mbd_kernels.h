@@ -1331,27 +1331,93 @@ __global__ __launch_bounds__(kWmE * kWmG) void wmean_kernel(const float* __restr
                                                             const float* __restrict__ Ybar_i, float alpha_i,
                                                             float alpha_bar_i, float alpha_bar_im1, int literal,
                                                             float* __restrict__ Ybar_im1) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // the N weights: read once, shared by the 16 outputs
   __shared__ float red[kWmG][kWmE + 1];
   const int j = threadIdx.x & (kWmE - 1), g = threadIdx.x / kWmE;
   const int e_raw = blockIdx.x * kWmE + j;
   const int e = e_raw < HNu ? e_raw : HNu - 1;
   const float* __restrict__ col = Y0s + e;
+  for (int i = threadIdx.x; i < N; i += kWmE * kWmG) wl[i] = weights[i];
+  __syncthreads();
   float acc = 0.0f;
   int n = g;
-  for (; n + 15 * kWmG < N; n += 16 * kWmG) {
-    float y[16], wv[16];
+  // the chain over n is sequential by contract, its loads are not: a thread keeps 32 rows of Y0s in flight while
+  // there are that many, then 16, then the tail (the kernel is bound by memory round trips per batch, not by
+  // bandwidth — multi-GPU plans average over all N_total candidates on every rank).  The scheduling barrier keeps
+  // the compiler from interleaving loads and the dependent fma chain at a shallower depth.
+  for (; n + 31 * kWmG < N; n += 32 * kWmG) {
+    float y[32];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) { y[k] = col[(size_t)(n + k * kWmG) * HNu]; wv[k] = weights[n + k * kWmG]; }
+    for (int k = 0; k < 32; ++k) y[k] = col[(size_t)(n + k * kWmG) * HNu];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc = ffma(wv[k], y[k], acc);
+    for (int k = 0; k < 32; ++k) acc = ffma(wl[n + k * kWmG], y[k], acc);
   }
-  for (; n < N; n += kWmG) acc = ffma(weights[n], col[(size_t)n * HNu], acc);
+  for (; n + 15 * kWmG < N; n += 16 * kWmG) {
+    float y[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) y[k] = col[(size_t)(n + k * kWmG) * HNu];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = ffma(wl[n + k * kWmG], y[k], acc);
+  }
+  for (; n < N; n += kWmG) acc = ffma(wl[n], col[(size_t)n * HNu], acc);
   red[g][j] = acc;
   __syncthreads();
   if (g != 0 || e_raw >= HNu) return;
   float tot = red[0][j];
 #pragma unroll 8
   for (int k = 1; k < kWmG; ++k) tot = tot + red[k][j];
+  float out = tot;
+  if (literal) {
+    const float sab = fsqrt(alpha_bar_i);
+    float Yi = Ybar_i[e] * sab;
+    float t1 = 1.0f / (1.0f - alpha_bar_i);
+    float t2 = sab * tot;
+    float score = t1 * (-Yi + t2);
+    float t3 = (1.0f - alpha_bar_i) * score;
+    float Yim1 = (1.0f / fsqrt(alpha_i)) * (Yi + t3);
+    out = Yim1 / fsqrt(alpha_bar_im1);
+  }
+  Ybar_im1[e] = out;
+}
+
+// The same weighted mean for LARGE N (multi-GPU plans average over all N_total candidates on every rank).  The tile
+// kernel above reads 64-byte pieces of rows 3.4 KB apart (1.4 TB/s at N = 8192); here a workgroup owns ONE candidate
+// group g and 256 consecutive outputs, so a wavefront reads 256 contiguous bytes of a row per load and the weight is a
+// scalar.  The (group, output) partials go through a [64][HNu] scratch and wmean_finish_kernel adds the 64 partials
+// of an output in group order and applies the update: the same chains and the same final order as wmean_kernel —
+// the same bits.
+constexpr int kWmT = 256;  // outputs per workgroup of the row-major variant
+__global__ __launch_bounds__(kWmT) void wmean_partial_kernel(const float* __restrict__ weights,
+                                                             const float* __restrict__ Y0s, int N, int HNu,
+                                                             float* __restrict__ partial) {
+  const int g = blockIdx.y;
+  const int e_raw = blockIdx.x * kWmT + threadIdx.x;
+  const int e = e_raw < HNu ? e_raw : HNu - 1;
+  const float* __restrict__ col = Y0s + e;
+  float acc = 0.0f;
+  int n = g;
+  for (; n + 31 * kWmG < N; n += 32 * kWmG) {
+    float y[32];
+#pragma unroll
+    for (int k = 0; k < 32; ++k) y[k] = col[(size_t)(n + k * kWmG) * HNu];
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int k = 0; k < 32; ++k) acc = ffma(weights[n + k * kWmG], y[k], acc);
+  }
+  for (; n < N; n += kWmG) acc = ffma(weights[n], col[(size_t)n * HNu], acc);
+  if (e_raw < HNu) partial[(size_t)g * HNu + e_raw] = acc;
+}
+__global__ __launch_bounds__(64) void wmean_finish_kernel(const float* __restrict__ partial, int HNu,
+                                                          const float* __restrict__ Ybar_i, float alpha_i,
+                                                          float alpha_bar_i, float alpha_bar_im1, int literal,
+                                                          float* __restrict__ Ybar_im1) {
+  const int e = blockIdx.x * 64 + threadIdx.x;
+  if (e >= HNu) return;
+  float tot = partial[e];
+#pragma unroll 8
+  for (int k = 1; k < kWmG; ++k) tot = tot + partial[(size_t)k * HNu + e];
   float out = tot;
   if (literal) {
     const float sab = fsqrt(alpha_bar_i);
