@@ -67,11 +67,19 @@ enum mbd_reward_kind {
   MBD_REW_CARTPOLE = 5       /* mbd/envs/cartpole.py:45: cos(q[1]) - |qd[0]| (hinge of link 1, slide of link 0) */
 };
 
+enum mbd_model_flags {
+  MBD_FLAG_RESET_QUAT_RAW = 1 /* reset(): leave the noise-perturbed root quaternion un-normalised (humanoidrun.py:24-26
+                                 perturbs all 7 root coordinates; whether kinematics.forward renormalises is unverified).
+                                 Default 0: normalised.                                                          */
+};
+
 typedef struct mbd_model {
   /* sizes */
   int32_t n_links, n_q, n_qd, n_act, n_col, n_track, n_frames, reward_kind;
   int32_t iso_inertia; /* 1: every inv_inertia is s*identity (spring_inertia_scale = 1 models)    */
-  int32_t reserved_i[3];
+  int32_t flags;       /* mbd_model_flags: named switches for the places where this engine had to GUESS what
+                          Brax does — flipping one is a recompile of the model, not of the code */
+  int32_t reserved_i[2];
   /* solver scalars */
   float dt;            /* physics substep (opt.timestep); control dt = dt * n_frames                */
   float vel_fac;       /* exp(vel_damping * dt)                                                     */

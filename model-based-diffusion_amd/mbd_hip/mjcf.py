@@ -233,9 +233,19 @@ def _fuse(b: _Body) -> None:
 def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Optional[str] = None,
          track_names: Sequence[str] = (), reset_noise: float = 0.0,
          reward_params: Sequence[float] = (), dt_override: Optional[float] = None,
-         init_q_offset: Sequence[float] = (), gear_override: Sequence[float] = ()) -> Model:
+         init_q_offset: Sequence[float] = (), gear_override: Sequence[float] = (),
+         passive_joint_forces: bool = True, reset_quat_raw: bool = False) -> Model:
     """Compile an MJCF file. ``n_frames`` is the env's physics substeps per control step
-    (humanoidrun.py:17 -> 7, humanoidtrack.py:46 -> 5, hopper.py:18 -> 20)."""
+    (humanoidrun.py:17 -> 7, humanoidtrack.py:46 -> 5, hopper.py:18 -> 20).
+
+    Named switches for the places where this engine had to GUESS what Brax does — each is a
+    recompile of the MODEL, the kernels and the checker stay as they are:
+      passive_joint_forces  MJCF joint ``stiffness`` / ``damping`` act as passive joint forces on top of the
+                            <custom> constraint_{ang,vel}_damping (default True); False zeroes them in the model.
+      reset_quat_raw        reset() leaves the noise-perturbed root quaternion un-normalised
+                            (MBD_FLAG_RESET_QUAT_RAW; default False: normalised).
+      gear_override         the env class's replacement of sys.actuator.gear (brax ant / half_cheetah).
+    Reward-side switches live in reward_params (ant: [5] = terminate_when_unhealthy)."""
     root = ET.parse(path).getroot()
     comp = root.find("compiler")
     angle_scale = 1.0 if (comp is not None and comp.get("angle", "degree") == "radian") else math.pi / 180
@@ -401,8 +411,8 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
             else:
                 lo, hi = -_BIG, _BIG
             F["rot_lo"][l, k], F["rot_hi"][l, k] = lo, hi
-            F["rot_stiff"][l, k] = float(j.get("stiffness", 0.0))
-            F["rot_damp"][l, k] = float(j.get("damping", 0.0))
+            F["rot_stiff"][l, k] = float(j.get("stiffness", 0.0)) if passive_joint_forces else 0.0
+            F["rot_damp"][l, k] = float(j.get("damping", 0.0)) if passive_joint_forces else 0.0
             joint_slot[j.get("name", f"{b.name}_h{k}")] = (l, k, s)
         for k, j in enumerate(slides):
             a = _floats(j.get("axis"), 3, np.array([0, 0, 1.0]))
@@ -412,7 +422,7 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
             limited = j.get("limited")
             if (limited == "true" or (limited not in ("true", "false") and "range" in j)) and "range" in j:
                 F["slide_lo"][l, k], F["slide_hi"][l, k] = _floats(j["range"], 2)
-            F["slide_damp"][l, k] = float(j.get("damping", 0.0))
+            F["slide_damp"][l, k] = float(j.get("damping", 0.0)) if passive_joint_forces else 0.0
             if float(j.get("stiffness", 0.0)) != 0.0:
                 raise ValueError(f"body {b.name!r}: slide joint stiffness is outside the hot-path subset")
             joint_slot[j.get("name", f"{b.name}_s{k}")] = (l, 3 + k, 1.0)
@@ -471,6 +481,7 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
     F.update(
         n_links=L, n_q=nq, n_qd=nqd, n_act=len(act_link), n_col=len(col_link), n_track=len(track),
         n_frames=int(n_frames), reward_kind=REWARD_KINDS.get(env_name, 0), iso_inertia=int(iso),
+        flags=int(1 if reset_quat_raw else 0),
         dt=np.float32(dt), vel_fac=np.float32(math.exp(custom["vel_damping"] * dt)),
         ang_fac=np.float32(math.exp(custom["ang_damping"] * dt)),
         joint_scale_pos=np.float32(custom["joint_scale_pos"]),

@@ -31,7 +31,7 @@ class MbdModel(C.Structure):
 
     _fields_ = [
         ("n_links", _i), ("n_q", _i), ("n_qd", _i), ("n_act", _i), ("n_col", _i), ("n_track", _i),
-        ("n_frames", _i), ("reward_kind", _i), ("iso_inertia", _i), ("reserved_i", _i * 3),
+        ("n_frames", _i), ("reward_kind", _i), ("iso_inertia", _i), ("flags", _i), ("reserved_i", _i * 2),
         ("dt", _f), ("vel_fac", _f), ("ang_fac", _f), ("joint_scale_pos", _f), ("joint_scale_ang", _f),
         ("collide_scale", _f), ("friction", _f), ("elasticity", _f), ("gravity", _f * 3),
         ("reset_noise", _f), ("reward_params", _f * 8),
@@ -56,7 +56,7 @@ class MbdModel(C.Structure):
 
 
 _SCALARS = ["n_links", "n_q", "n_qd", "n_act", "n_col", "n_track", "n_frames", "reward_kind",
-            "iso_inertia", "dt", "vel_fac", "ang_fac", "joint_scale_pos", "joint_scale_ang",
+            "iso_inertia", "flags", "dt", "vel_fac", "ang_fac", "joint_scale_pos", "joint_scale_ang",
             "collide_scale", "friction", "elasticity", "reset_noise"]
 _ARRAYS = [n for n, _t in MbdModel._fields_ if n not in _SCALARS and n != "reserved_i"]
 
@@ -92,7 +92,7 @@ class Model:
     def to_struct(self) -> MbdModel:
         s = MbdModel()
         for name in _SCALARS:
-            setattr(s, name, self.fields[name])
+            setattr(s, name, self.fields.get(name, 0) if name == "flags" else self.fields[name])
         for name in _ARRAYS:
             ctype_arr = getattr(s, name)
             dst = np.ctypeslib.as_array(ctype_arr)
@@ -136,6 +136,7 @@ class Model:
         d = json.loads(text)
         fields: Dict[str, Any] = {}
         ftypes = dict((n, t) for n, t in MbdModel._fields_)
+        fields["flags"] = 0  # (models compiled before the field existed)
         for k, v in d["fields"].items():
             if isinstance(v, list):
                 base = ftypes[k]

@@ -161,6 +161,22 @@ typedef struct {
 /* ------------------------------------------------------------------------------------------------ */
 /* one physics substep (brax/positional/pipeline.py::step)                                           */
 /* ------------------------------------------------------------------------------------------------ */
+/* stage dump (tools/compare_golden.py): after each of the six stages the link records [L][13] =
+ * (p, r, v, w) as they stand there; stage (1) puts the joint accelerations (before gravity) in the v / w slots. */
+static float* g_stage_dump = 0;
+#ifdef _OPENMP
+#pragma omp threadprivate(g_stage_dump)
+#endif
+static void dump_stage(int stage, int L, const xf_t* x, const mo_t* xd) {
+  if (!g_stage_dump) return;
+  float* o = g_stage_dump + (size_t)stage * L * MBD_LINK_STATE;
+  for (int l = 0; l < L; ++l) {
+    float* a = o + l * MBD_LINK_STATE;
+    for (int i = 0; i < 3; ++i) { a[i] = (float)x[l].p[i]; a[7 + i] = (float)xd[l].v[i]; a[10 + i] = (float)xd[l].w[i]; }
+    for (int i = 0; i < 4; ++i) a[3 + i] = (float)x[l].r[i];
+  }
+}
+
 static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot /* [L][3] */,
                     const real* tau_slide /* [L][3] */) {
   const int L = m->n_links;
@@ -223,11 +239,14 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
   }
   /* ---- (2) integrator.integrate_xdd: damp, accelerate (+gravity), integrate pose */
   xf_t x_prev[MBD_MAX_LINKS];
+  mo_t acc_dump[MBD_MAX_LINKS];
+  memset(x_prev, 0, sizeof(x_prev)); memset(acc_dump, 0, sizeof(acc_dump));
   for (int l = 0; l < L; ++l) {
     real av[3], aw[3];
     sp_copy3(fc_v[l], av); sp_copy3(fc_w[l], aw);
     for (int c = l + 1; c < L; ++c)
       if (m->parent[c] == l) { sp_add3(av, fp_v[c], av); sp_add3(aw, fp_w[c], aw); }
+    sp_copy3(av, acc_dump[l].v); sp_copy3(aw, acc_dump[l].w);
     for (int i = 0; i < 3; ++i) {
       xd[l].v[i] = sp_fma(av[i] + R(m->gravity[i]), dt, R(m->vel_fac) * xd[l].v[i]);
       xd[l].w[i] = sp_fma(aw[i], dt, R(m->ang_fac) * xd[l].w[i]);
@@ -238,6 +257,8 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_scale3(xd[l].w, dt, th);
     sp_qrotvec(x[l].r, th);
   }
+  dump_stage(0, L, x_prev, acc_dump); /* (1): poses before the step, accelerations in the velocity slots */
+  dump_stage(1, L, x, xd);            /* (2) */
   /* ---- (3) joints.position_update (Jacobi: every joint sees the same post-integration poses) */
   for (int l = 0; l < L; ++l) inert_refresh(&in[l], x[l].r);
   real dc_p[MBD_MAX_LINKS][3], dc_th[MBD_MAX_LINKS][3], dp_p[MBD_MAX_LINKS][3], dp_th[MBD_MAX_LINKS][3];
@@ -350,6 +371,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_add3(x[l].p, dp, x[l].p);
     sp_qrotvec_raw(x[l].r, dth); /* renormalised at the end of stage (4) */
   }
+  dump_stage(2, L, x, xd); /* (3) */
   /* ---- (4) geometry.contact (sphere-plane) + collisions.resolve_position */
   for (int l = 0; l < L; ++l) inert_refresh(&in[l], x[l].r); /* (not yet renormalised, like the contact points) */
   contact_t con[MBD_MAX_COL];
@@ -400,6 +422,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_add3(x[l].p, cd_p[l], x[l].p);
     sp_qrotvec(x[l].r, cd_th[l]);
   }
+  dump_stage(3, L, x, xd); /* (4) */
   /* ---- (5) integrator.project_xd: velocities from the position change */
   mo_t xd_prev[MBD_MAX_LINKS];
   for (int l = 0; l < L; ++l) {
@@ -410,6 +433,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     real s = (dq[0] < R(0) ? R(-2) : R(2)) * inv_dt;
     for (int i = 0; i < 3; ++i) xd[l].w[i] = dq[1 + i] * s;
   }
+  dump_stage(4, L, x, xd); /* (5) */
   /* ---- (6) collisions.resolve_velocity: restitution + dynamic friction at active contacts */
   for (int l = 0; l < L; ++l) inert_refresh(&in[l], x[l].r);
   for (int k = 0; k < m->n_col; ++k) {
@@ -438,6 +462,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     real mom[3];
     sp_cross3(rc, Pimp, mom); iinv_apply(&in[l], mom, t); sp_add3(xd[l].w, t, xd[l].w);
   }
+  dump_stage(5, L, x, xd); /* (6) */
 }
 
 /* ---- state <-> float buffers -------------------------------------------------------------------- */
@@ -553,6 +578,14 @@ ORC_API void orc_substep(const mbd_model_t* m, const float* state_in, const floa
   store_state(state_out, m->n_links, x, xd);
 }
 
+/* one substep with the state after each of the six stages: stages [6][L][13] (see dump_stage) */
+ORC_API void orc_substep_stages(const mbd_model_t* m, const float* state_in, const float* action, float* state_out,
+                                float* stages) {
+  g_stage_dump = stages;
+  orc_substep(m, state_in, action, state_out);
+  g_stage_dump = 0;
+}
+
 /* jax.vmap(rollout_us, in_axes=(None, 0)) (mbd_planner.py:109; utils.py:14-20): the reward and the
  * tracked link positions AFTER every control step. Single-threaded (cores = 1) unless built with
  * -fopenmp, in which case candidates are distributed over threads. */
@@ -599,7 +632,7 @@ ORC_API void orc_forward(const mbd_model_t* m, const float* q, const float* qd, 
     if (m->n_rot[l] < 0) { /* free joint: q = pos, quat ; qd = vel, ang */
       for (int i = 0; i < 3; ++i) { X[l].p[i] = ql[i]; V[l][i] = qdl[i]; W[l][i] = qdl[3 + i]; }
       for (int i = 0; i < 4; ++i) X[l].r[i] = ql[3 + i];
-      sp_qnormalize(X[l].r); /* deviation candidate: brax may leave the reset quaternion un-normalised */
+      if (!(m->flags & MBD_FLAG_RESET_QUAT_RAW)) sp_qnormalize(X[l].r); /* (brax may leave it un-normalised) */
     } else {
       real jpos[3] = {0, 0, 0}, jrot[4] = {1, 0, 0, 0}, sv[3] = {0, 0, 0}, wrel[3] = {0, 0, 0};
       const int ns = m->n_slide[l], nr = m->n_rot[l];

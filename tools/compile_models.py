@@ -42,7 +42,9 @@ def main():
                       track_names=spec.get("track", ()), reset_noise=spec["reset_noise"],
                       reward_params=spec.get("reward_params", ()), dt_override=spec.get("dt_override"),
                       init_q_offset=spec.get("init_q_offset", ()),
-                      gear_override=spec.get("gear_override", ()))
+                      gear_override=spec.get("gear_override", ()),
+                      passive_joint_forces=spec.get("passive_joint_forces", True),
+                      reset_quat_raw=spec.get("reset_quat_raw", False))
         with open(os.path.join(out, f"{name}.json"), "w") as f:
             f.write(m.to_json())
         print(f"{name}: L={m.n_links} nq={m.q_size()} nqd={m.qd_size()} nu={m.act_size()} "
