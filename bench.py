@@ -8,8 +8,9 @@
 A "step" is one reverse-diffusion step (mbd_planner.py:97-135): sample N candidates, roll them out
 H control steps through the positional rigid-body simulator, score, softmax, weighted mean — PLUS the
 host read of the step's mean reward that the reference's progress bar forces every step
-(mbd_planner.py:147; SURVEY.md §8(d) defines the metric with that sync inside).  `value` is measured
-with the per-step read; `value_async` (same K steps, reads dropped) is reported beside it.
+(mbd_planner.py:147; SURVEY.md §8(d) defines the metric with that read inside): the host does not dispatch
+step k+1 before it holds step k's mean reward.  `value` is measured with the per-step read; `value_async`
+(same K steps, reads dropped) is reported beside it.
 
 --config (default `metric`, the configuration BASELINE.json's metric is quoted on):
    metric            humanoidrun  N=1024 H=50 temp 0.1
@@ -216,7 +217,7 @@ def main():
 
     from mbd_hip import _capi
     from mbd_hip.envs import get_env
-    from mbd_hip.planners.mbd_planner import Args, Plan, run_diffusion
+    from mbd_hip.planners.mbd_planner import Args, HostProgress, Plan, run_diffusion
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
     env = get_env(ENV, device=local_rank)
@@ -242,6 +243,9 @@ def main():
         allv = torch.zeros((rows, N_total), dtype=torch.float32, device=dev)
         gath = torch.zeros((max(world, 1) * rows, N_local), dtype=torch.float32, device=dev)
         rew_mean = torch.zeros(1, dtype=torch.float32, device=dev)
+        # the per-step host read (mbd_planner.py:147) without a stream synchronisation: the score kernel stores the
+        # step's mean reward into a pinned host slot and the host spins on it (mbd_hip HostProgress)
+        host = HostProgress(1, dev)
         st = {"rng": np.asarray(rng_exp, np.uint32), "i": ND - 1, "Ybar": Ybar, "Ynext": Ynext}
 
         def step(read_back):
@@ -259,19 +263,21 @@ def main():
                     gath.view(1, N_total)
                 src = src.contiguous() if rows > 1 else src
             elif distributed:  # gloo dry run: stage through the host
-                host = torch.empty((world * rows, N_local), dtype=torch.float32)
-                dist.all_gather_into_tensor(host, local.cpu())
-                allv.copy_(host.view(world, rows, N_local).permute(1, 0, 2).reshape(rows, N_total))
+                staged = torch.empty((world * rows, N_local), dtype=torch.float32)
+                dist.all_gather_into_tensor(staged, local.cpu())
+                allv.copy_(staged.view(world, rows, N_local).permute(1, 0, 2).reshape(rows, N_total))
                 src = allv
             else:
                 src = local
+            if read_back:
+                host.reset(0)
             _capi.check(lib.mbd_plan_score_update(plan.h, i, ks, Yb.data_ptr(), src[0].data_ptr(),
                                                   src[1].data_ptr() if DEMO else None, st["Ynext"].data_ptr(),
-                                                  rew_mean.data_ptr(), stream))
+                                                  host.ptr(0) if read_back else rew_mean.data_ptr(), stream))
             st["Ybar"], st["Ynext"] = st["Ynext"], st["Ybar"]
             st["i"] = i - 1
-            if read_back:  # pbar.set_postfix({"rew": f"{rew:.2e}"}) (mbd_planner.py:147): a device->host read per step
-                return float(rew_mean.item())
+            if read_back:  # pbar.set_postfix({"rew": f"{rew:.2e}"}) (mbd_planner.py:147): the host has the step's
+                return host.wait(0)  # mean reward in hand before it dispatches the next step
             return None
 
         def fence():

@@ -139,6 +139,38 @@ class Plan:
             pass
 
 
+class HostProgress:
+    """The per-step mean rewards the reference shows on its progress bar (mbd_planner.py:147), delivered WITHOUT a
+    stream synchronisation: one slot per diffusion step in pinned, device-visible host memory, pre-filled with NaN;
+    ``mbd_plan_score_update`` is handed the slot's address as its ``d_rew_mean`` and the score kernel's own store
+    lands there.  ``wait(k)`` spins on the slot (falling back to a device synchronisation after ``timeout_s``, e.g.
+    when the mean itself is NaN); the device meanwhile runs on into the weighted mean and the next step."""
+
+    def __init__(self, n: int, device):
+        import torch
+        self.t = torch.full((max(n, 1),), float("nan"), dtype=torch.float32).pin_memory()
+        self.v = self.t.numpy()
+        self.device = device
+
+    def ptr(self, k: int) -> int:
+        return self.t.data_ptr() + 4 * k
+
+    def reset(self, k: int) -> None:
+        self.v[k] = np.nan
+
+    def wait(self, k: int, timeout_s: float = 2.0) -> float:
+        import torch
+        v, t0, spins = self.v, None, 0
+        while v[k] != v[k]:  # NaN: not written yet
+            spins += 1
+            if spins & 0xfff == 0:
+                t0 = t0 or time.perf_counter()
+                if time.perf_counter() - t0 > timeout_s:
+                    torch.cuda.synchronize(self.device)
+                    break
+        return float(v[k])
+
+
 def shard_bounds(N: int, world: int, rank: int):
     """Candidates [begin, begin+count) owned by `rank`: contiguous, equal shards (N % world == 0)."""
     if N % world:
@@ -196,6 +228,7 @@ def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bo
     lib = plan.lib
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if phase_times is not None else None
     acc = [0.0, 0.0, 0.0]
+    host = HostProgress(plan.Nd - 1, dev) if (sync_every_step or progress is not None) else None
     for i in range(plan.Nd - 1, 0, -1):
         keys = _capi.prng_split(rng, 2, impl)  # rng, Y0s_rng = split(rng)  (mbd_planner.py:103)
         rng, ks = keys[0], _capi.key_array(keys[1])
@@ -209,22 +242,26 @@ def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bo
         if ev:
             ev[2].record()
         out = mu[plan.Nd - 1 - i]
+        k = plan.Nd - 1 - i
         _capi.check(lib.mbd_plan_score_update(plan.h, i, ks, Ybar.data_ptr(), allv[0].data_ptr(),
                                               allv[1].data_ptr() if demo else None, out.data_ptr(),
-                                              rew_means[plan.Nd - 1 - i:].data_ptr(), stream))
+                                              host.ptr(k) if host else rew_means[k:].data_ptr(), stream))
         Ybar = out
         if ev:
             ev[3].record()
             ev[3].synchronize()
             for k in range(3):
                 acc[k] += ev[k].elapsed_time(ev[k + 1])
-        if sync_every_step or progress is not None:  # the reference formats the reward every step (:147)
-            r = float(rew_means[plan.Nd - 1 - i])
+        if host is not None:  # the reference formats the reward every step (:147): one host read per step
+            r = host.wait(k)
             if progress is not None:
                 progress(i, r)
     if phase_times is not None:
         n = max(plan.Nd - 1, 1)
         phase_times.update(phase1_ms=acc[0] / n, exchange_ms=acc[1] / n, phase2_ms=acc[2] / n, steps=plan.Nd - 1)
+    if host is not None:
+        torch.cuda.synchronize(dev)
+        rew_means.copy_(host.t[: plan.Nd - 1])
     return mu.view(plan.Nd - 1, plan.H, plan.Nu), rew_means
 
 
