@@ -171,11 +171,32 @@ struct WInert {
 };
 // DIAG: every body-frame tensor of the model is exactly diagonal (axis-aligned capsules / boxes): the products
 // with the zero off-diagonal entries are dropped — same values, 27 instructions fewer per tensor.
-template <bool ISO, bool DIAG>
+// AXI: every body-frame tensor is axisymmetric about one of the link's axes — diag with two equal entries (capsules:
+// hopper, walker2d): Ib = a Id + (c - a) u u^T, so the world tensor is a Id + (c - a) U U^T with U = R u.  Only U is
+// rebuilt per stage (one rotation of a constant instead of R Ib R^T) and the tensor is applied as
+// a v + (c - a)(U.v) U — a specification of its own (not the same roundings as R Ib R^T), shared with the checker.
+// The lane constants are remapped once: ib = (a, a, c, u.x, u.y, u.z).
+template <bool ISO>
+__device__ __forceinline__ float axi_k(const Inert<ISO>& in) { return in.ib[ISO ? 0 : 2] - in.ib[0]; }
+template <bool ISO>
+__device__ __forceinline__ void axi_remap(Inert<ISO>& in) {
+  if constexpr (!ISO) {
+    const float xx = in.ib[0], yy = in.ib[1], zz = in.ib[2];
+    const bool ez = xx == yy, ex = !ez && yy == zz;  // otherwise xx == zz: the axis is y
+    const float a = ez ? xx : (ex ? yy : xx), c = ez ? zz : (ex ? xx : yy);
+    in.ib[0] = a; in.ib[1] = a; in.ib[2] = c;
+    in.ib[3] = ex ? 1.0f : 0.0f; in.ib[4] = (!ez && !ex) ? 1.0f : 0.0f; in.ib[5] = ez ? 1.0f : 0.0f;
+  }
+}
+template <bool ISO, bool DIAG, bool AXI = false>
 __device__ __forceinline__ WInert<ISO> world_inertia(const Inert<ISO>& in, q4 r) {
   WInert<ISO> W;
   if constexpr (ISO) {
     W.w[0] = 0.0f;
+  } else if constexpr (AXI) {
+    const v3 U = rot(v3{in.ib[3], in.ib[4], in.ib[5]}, r);
+    W.w[0] = U.x; W.w[1] = U.y; W.w[2] = U.z;
+    W.w[3] = W.w[4] = W.w[5] = 0.0f;
   } else if constexpr (DIAG) {
     const axes3 A = qaxes(r);
     const float xx = in.ib[0], yy = in.ib[1], zz = in.ib[2];
@@ -206,10 +227,14 @@ __device__ __forceinline__ WInert<ISO> world_inertia(const Inert<ISO>& in, q4 r)
   return W;
 }
 // world-frame inverse inertia applied to v
-template <bool ISO>
+template <bool ISO, bool AXI = false>
 __device__ __forceinline__ v3 iinv(const Inert<ISO>& in, const WInert<ISO>& W, v3 v) {
   if constexpr (ISO) {
     return scale(v, in.ib[0]);
+  } else if constexpr (AXI) {
+    const v3 Z = v3{W.w[0], W.w[1], W.w[2]};
+    const float kd = axi_k<ISO>(in) * dot(Z, v);
+    return v3{ffma(kd, Z.x, in.ib[0] * v.x), ffma(kd, Z.y, in.ib[0] * v.y), ffma(kd, Z.z, in.ib[0] * v.z)};
   } else {
     v3 m;
     m.x = ffma(W.w[4], v.z, ffma(W.w[3], v.y, W.w[0] * v.x));
@@ -281,11 +306,15 @@ template <bool ISO>
 struct WInert2 {
   f2 w[ISO ? 1 : 6];
 };
-template <bool ISO, bool DIAG>
+template <bool ISO, bool DIAG, bool AXI = false>
 __device__ __forceinline__ WInert2<ISO> world_inertia2(const Inert<ISO>& ip, const Inert<ISO>& ic, q4x2 R2) {
   WInert2<ISO> W;
   if constexpr (ISO) {
     W.w[0] = mk2(0.0f, 0.0f);
+  } else if constexpr (AXI) {
+    const v3x2 U = rot2(pack3(v3{ip.ib[3], ip.ib[4], ip.ib[5]}, v3{ic.ib[3], ic.ib[4], ic.ib[5]}), R2);
+    W.w[0] = U.x; W.w[1] = U.y; W.w[2] = U.z;
+    W.w[3] = W.w[4] = W.w[5] = mk2(0.0f, 0.0f);
   } else if constexpr (DIAG) {
     const axes3x2 A = qaxes2(R2);
     const f2 xx = mk2(ip.ib[0], ic.ib[0]), yy = mk2(ip.ib[1], ic.ib[1]), zz = mk2(ip.ib[2], ic.ib[2]);
@@ -316,10 +345,15 @@ __device__ __forceinline__ WInert2<ISO> world_inertia2(const Inert<ISO>& ip, con
   }
   return W;
 }
-template <bool ISO>
+template <bool ISO, bool AXI = false>
 __device__ __forceinline__ v3x2 iinv2(const Inert<ISO>& ip, const Inert<ISO>& ic, const WInert2<ISO>& W, v3x2 v) {
   if constexpr (ISO) {
     return scale2(v, mk2(ip.ib[0], ic.ib[0]));
+  } else if constexpr (AXI) {
+    const v3x2 Z = v3x2{W.w[0], W.w[1], W.w[2]};
+    const f2 a = mk2(ip.ib[0], ic.ib[0]);
+    const f2 kd = mk2(axi_k<ISO>(ip), axi_k<ISO>(ic)) * dot2(Z, v);
+    return v3x2{fma2(kd, Z.x, a * v.x), fma2(kd, Z.y, a * v.y), fma2(kd, Z.z, a * v.z)};
   } else {
     v3x2 m;
     m.x = fma2(W.w[4], v.z, fma2(W.w[3], v.y, W.w[0] * v.x));
@@ -335,12 +369,12 @@ struct AngPrep {
   v3x2 in2;  // (I_p^-1 e, I_c^-1 e)
   float num, den;
 };
-template <bool ISO>
+template <bool ISO, bool AXI = false>
 __device__ __forceinline__ AngPrep ang_prepare(v3 e, const Inert<ISO>& ip, const Inert<ISO>& ic,
                                                const WInert2<ISO>& W2) {
   AngPrep a;
   v3x2 e2 = bcast3(e);
-  a.in2 = iinv2<ISO>(ip, ic, W2, e2);
+  a.in2 = iinv2<ISO, AXI>(ip, ic, W2, e2);
   f2 d2 = dot2(e2, a.in2);
   a.den = (d2.x + d2.y) + 1e-20f;
   a.num = dot(e, e);
@@ -358,10 +392,13 @@ __device__ __forceinline__ float dot_az0(v3 a, v3 b) { return ffma(a.x, b.x, a.y
 __device__ __forceinline__ v3 cross_bz0(v3 a, v3 b) {
   return v3{-(a.z * b.y), a.z * b.x, ffma(a.x, b.y, -(a.y * b.x))};
 }
-template <bool ISO>
+template <bool ISO, bool AXI = false>
 __device__ __forceinline__ v3 iinv_z0(const Inert<ISO>& in, const WInert<ISO>& W, v3 v) {
   if constexpr (ISO) {
     return v3{v.x * in.ib[0], v.y * in.ib[0], 0.0f};
+  } else if constexpr (AXI) {
+    const float kd = axi_k<ISO>(in) * ffma(W.w[0], v.x, W.w[1] * v.y);
+    return v3{ffma(kd, W.w[0], in.ib[0] * v.x), ffma(kd, W.w[1], in.ib[0] * v.y), kd * W.w[2]};
   } else {
     return v3{ffma(W.w[3], v.y, W.w[0] * v.x), ffma(W.w[1], v.y, W.w[3] * v.x), ffma(W.w[5], v.y, W.w[4] * v.x)};
   }
@@ -376,10 +413,15 @@ __device__ __forceinline__ v3x2 irot_z2(f2 d, q4x2 q) {
   f2 cx = q.z * ty, cy = -(q.z * tx), cz = fma2(-q.x, ty, q.y * tx);
   return v3x2{fma2(q.w, tx, cx), fma2(q.w, ty, cy), d + cz};
 }
-template <bool ISO>
+template <bool ISO, bool AXI = false>
 __device__ __forceinline__ v3x2 iinv_s2(const Inert<ISO>& in, const WInert<ISO>& W, v3x2 v) {
   if constexpr (ISO) {
     return scale2(v, mk2(in.ib[0], in.ib[0]));
+  } else if constexpr (AXI) {
+    const v3x2 Z = bcast3(v3{W.w[0], W.w[1], W.w[2]});
+    const f2 a = mk2(in.ib[0], in.ib[0]), k = mk2(axi_k<ISO>(in), axi_k<ISO>(in));
+    const f2 kd = k * dot2(Z, v);
+    return v3x2{fma2(kd, Z.x, a * v.x), fma2(kd, Z.y, a * v.y), fma2(kd, Z.z, a * v.z)};
   } else {
     auto b = [&](int k) { return mk2(W.w[k], W.w[k]); };
     v3x2 m;
@@ -389,11 +431,16 @@ __device__ __forceinline__ v3x2 iinv_s2(const Inert<ISO>& in, const WInert<ISO>&
     return m;
   }
 }
-template <bool ISO>
+template <bool ISO, bool AXI = false>
 __device__ __forceinline__ v3x2 iinv_z0_s2(const Inert<ISO>& in, const WInert<ISO>& W, v3x2 v) {
   if constexpr (ISO) {
     const f2 ib = mk2(in.ib[0], in.ib[0]);
     return v3x2{v.x * ib, v.y * ib, mk2(0.0f, 0.0f)};
+  } else if constexpr (AXI) {
+    const f2 Zx = mk2(W.w[0], W.w[0]), Zy = mk2(W.w[1], W.w[1]), Zz = mk2(W.w[2], W.w[2]);
+    const f2 a = mk2(in.ib[0], in.ib[0]), k = mk2(axi_k<ISO>(in), axi_k<ISO>(in));
+    const f2 kd = k * fma2(Zx, v.x, Zy * v.y);
+    return v3x2{fma2(kd, Zx, a * v.x), fma2(kd, Zy, a * v.y), kd * Zz};
   } else {
     auto b = [&](int k) { return mk2(W.w[k], W.w[k]); };
     return v3x2{fma2(b(3), v.y, b(0) * v.x), fma2(b(1), v.y, b(3) * v.x), fma2(b(5), v.y, b(4) * v.x)};
@@ -416,7 +463,7 @@ __device__ __forceinline__ v3x2 cross_bz0_2(v3x2 a, v3x2 b) {
 //       frame is the constant ap_rot (identity (x) ap_rot, up to the sign of zeros), so the world-frame slide axes
 //       rot(slide_axis, aprot) are per-lane constants instead of a rotation per slot, stage and substep
 template <int LPS, bool ISO, bool SLIDES, int MAXCH, int MAXCOL, int D0 = 0, int D1 = 0, int D2 = 0, int D3 = 0,
-          bool DIAG = false, bool MULTI = true, int NS = 3, bool SLIDEW = false>
+          bool DIAG = false, bool MULTI = true, int NS = 3, bool SLIDEW = false, bool AXI = false>
 __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
   constexpr bool DPP = D0 != 0;
   static_assert(!DPP || ((D1 != 0 || D2 == 0) && (D2 != 0 || D3 == 0) && (D3 == 0 || MAXCH >= 4)),
@@ -456,6 +503,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
     ic.ib[k] = M->inv_inertia[l][k];
     ip.ib[k] = world_parent ? 0.0f : M->inv_inertia[parent >= 0 ? parent : 0][k];
   }
+  if constexpr (AXI) { axi_remap<ISO>(ic); axi_remap<ISO>(ip); }
   JointConst jc;
   jc.ap_pos = mk3(M->ap_pos[l][0], M->ap_pos[l][1], M->ap_pos[l][2]);
   jc.ac_pos = mk3(M->ac_pos[l][0], M->ac_pos[l][1], M->ac_pos[l][2]);
@@ -645,7 +693,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
       v3 fc_v, fc_w, fp_v, fp_w;
       {
         JointFrames f = joint_frames(jc, Pp, Pr, p, r, multi);
-        const WInert2<ISO> W2 = world_inertia2<ISO, DIAG>(ip, ic, pack4(Pr, r));
+        const WInert2<ISO> W2 = world_inertia2<ISO, DIAG, AXI>(ip, ic, pack4(Pr, r));
         const v3x2 arm = f.arm;  // (rp, rc)
         shfl_join();
         const v3x2 va = add2(pack3(Pv, v), cross2(pack3(Pw, w), arm));  // anchor velocities (vp, vc)
@@ -678,7 +726,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         const v3x2 F2 = bcast3(F);
         const v3x2 lin = scale2(F2, mk2(-ip.inv_mass, ic.inv_mass));       // (fp_v, fc_v)
         const v3x2 tot = add2(bcast3(T), cross2(arm, F2));
-        const v3x2 ang = scale2(iinv2<ISO>(ip, ic, W2, tot), mk2(-1.0f, 1.0f));  // (fp_w, fc_w)
+        const v3x2 ang = scale2(iinv2<ISO, AXI>(ip, ic, W2, tot), mk2(-1.0f, 1.0f));  // (fp_w, fc_w)
         fc_v = hi3(lin); fp_v = lo3(lin);
         fc_w = hi3(ang); fp_w = lo3(ang);
       }
@@ -741,12 +789,12 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
             d = axpy(cf, s, d);
           }
         }
-        const WInert2<ISO> W2 = world_inertia2<ISO, DIAG>(ip, ic, pack4(Pr, r));
+        const WInert2<ISO> W2 = world_inertia2<ISO, DIAG, AXI>(ip, ic, pack4(Pr, r));
         const v3x2 arm = f.arm;  // (rp, rc)
         float c2 = dot(d, d);
         const v3x2 d2 = bcast3(d);
         const v3x2 cr = cross2(arm, d2);                       // (rp x d, rc x d)
-        const f2 wq = dot2(cr, iinv2<ISO>(ip, ic, W2, cr));
+        const f2 wq = dot2(cr, iinv2<ISO, AXI>(ip, ic, W2, cr));
         float den = ffma(invm_sum, c2, wq.x + wq.y) + 1e-20f;
         // angular alignment by joint type (0 hinges: weld; 1: Xc || Xp; 2: Yc _|_ Xp; 3: free)
         v3 A = sel3(nr == 1, f.Xc, f.Xp);
@@ -768,10 +816,10 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         AngPrep ca, c0, c1, c2_;
         v3 E = e;
         auto limits_prepare = [&] {
-          c0 = ang_prepare<ISO>(scale(f.Xp, -viol_of(0, f.ang0)), ip, ic, W2);
+          c0 = ang_prepare<ISO, AXI>(scale(f.Xp, -viol_of(0, f.ang0)), ip, ic, W2);
           if (multi) {
-            c1 = ang_prepare<ISO>(scale(f.ax1, -viol_of(1, f.ang1)), ip, ic, W2);
-            c2_ = ang_prepare<ISO>(scale(f.Zc, -viol_of(2, f.ang2)), ip, ic, W2);
+            c1 = ang_prepare<ISO, AXI>(scale(f.ax1, -viol_of(1, f.ang1)), ip, ic, W2);
+            c2_ = ang_prepare<ISO, AXI>(scale(f.Zc, -viol_of(2, f.ang2)), ip, ic, W2);
           }
         };
         f2 q_ta, q01;  // (translation, alignment) and (limit 0, limit 1) quotients
@@ -786,7 +834,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         } else if constexpr (DPP) {
           // no exchange latency to hide here: all divisions run as interleaved independent chains (a dependent
           // packed FMA costs a wait state, which the compiler fills with s_nop when nothing else is at hand)
-          ca = ang_prepare<ISO>(e, ip, ic, W2);
+          ca = ang_prepare<ISO, AXI>(e, ip, ic, W2);
           limits_prepare();
           if (multi) {
             div2x2_(mk2(c2, ca.num), mk2(den, ca.den), mk2(c0.num, c1.num), mk2(c0.den, c1.den), q_ta, q01);
@@ -797,13 +845,13 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
             q2 = 0.0f;
           }
         } else {
-          ca = ang_prepare<ISO>(e, ip, ic, W2);
+          ca = ang_prepare<ISO, AXI>(e, ip, ic, W2);
           q_ta = div2_pos_(mk2(c2, ca.num), mk2(den, ca.den));
         }
         float g = q_ta.x * js_pos;
         const v3x2 P2 = bcast3(scale(d, g));
         const v3x2 lin = scale2(P2, mk2(-ip.inv_mass, ic.inv_mass));  // (dp_p, dc_p)
-        v3x2 dth2 = scale2(iinv2<ISO>(ip, ic, W2, cross2(arm, P2)), mk2(-1.0f, 1.0f));  // (dp_th, dc_th)
+        v3x2 dth2 = scale2(iinv2<ISO, AXI>(ip, ic, W2, cross2(arm, P2)), mk2(-1.0f, 1.0f));  // (dp_th, dc_th)
         v3x2 lin2 = lin;
         // slide limits: push the child back along the slide axis by the violation. Models without a limited
         // slide (planar roots of hopper / walker2d / halfcheetah) skip the block: it would add exact zeros.
@@ -817,12 +865,12 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
             float l2 = dot(dl, dl);
             const v3x2 dl2 = bcast3(dl);
             const v3x2 lcr = cross2(arm, dl2);
-            const f2 lw = dot2(lcr, iinv2<ISO>(ip, ic, W2, lcr));
+            const f2 lw = dot2(lcr, iinv2<ISO, AXI>(ip, ic, W2, lcr));
             float dens = ffma(invm_sum, l2, lw.x + lw.y);
             float gs = div_pos_(l2, dens + 1e-20f) * js_pos;
             const v3x2 Ps2 = bcast3(scale(dl, gs));
             lin2 = add2(lin2, scale2(Ps2, mk2(-ip.inv_mass, ic.inv_mass)));
-            dth2 = add2(dth2, scale2(iinv2<ISO>(ip, ic, W2, cross2(arm, Ps2)), mk2(-1.0f, 1.0f)));
+            dth2 = add2(dth2, scale2(iinv2<ISO, AXI>(ip, ic, W2, cross2(arm, Ps2)), mk2(-1.0f, 1.0f)));
           }
         }
         // the translational corrections are final: the parent's share leaves now and its round trip hides
@@ -890,7 +938,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
       float con_dlam[MAXCOL];
       bool con_act[MAXCOL];
       {
-        const WInert<ISO> Wc = world_inertia<ISO, DIAG>(ic, r);  // (r not yet renormalised, like the contact points)
+        const WInert<ISO> Wc = world_inertia<ISO, DIAG, AXI>(ic, r);  // (r not yet renormalised, like the contact points)
         v3 cd_p = mk3(0, 0, 0), cd_th = mk3(0, 0, 0);
         if constexpr (MAXCOL == 2) {
           // both colliders of the link as one packed pair (the solve is Jacobi: each sees the pose of the stage's
@@ -906,7 +954,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           const v3x2 pos = v3x2{ctr.x, ctr.y, ctr.z - h};
           const v3x2 rc = v3x2{off.x, off.y, off.z - h};
           const v3x2 cn = v3x2{rc.y, -rc.x, mk2(0.0f, 0.0f)};
-          const v3x2 icn = iinv_z0_s2<ISO>(ic, Wc, cn);
+          const v3x2 icn = iinv_z0_s2<ISO, AXI>(ic, Wc, cn);
           const f2 wn = mk2(ic.inv_mass, ic.inv_mass) + dot_az0_2(cn, icn);
           const v3x2 rl = add2(cpos, irot_z2(-h, R2));
           const v3x2 pprev = add2(bcast3(p_prev), rot2(rl, bcast4(r_prev)));
@@ -914,7 +962,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           dx.z = mk2(0.0f, 0.0f);
           const f2 ct2 = fma2(dx.x, dx.x, dx.y * dx.y);
           const v3x2 cnt = cross_bz0_2(rc, dx);
-          const v3x2 icnt = iinv_s2<ISO>(ic, Wc, cnt);
+          const v3x2 icnt = iinv_s2<ISO, AXI>(ic, Wc, cnt);
           const f2 dent = fma2(mk2(ic.inv_mass, ic.inv_mass), ct2, dot2(cnt, icnt));
           f2 q_n, q_g;  // (dlam / collide_scale, gt) of both colliders
           div2x2_(pen, wn, ct2, dent + mk2(1e-20f, 1e-20f), q_n, q_g);
@@ -924,7 +972,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           const bool st0 = lhs.x < rhs.x, st1 = lhs.y < rhs.y;
           const f2 px = (-q_g) * dx.x, py = (-q_g) * dx.y;
           const v3x2 Pimp = v3x2{mk2(st0 ? px.x : 0.0f, st1 ? px.y : 0.0f), mk2(st0 ? py.x : 0.0f, st1 ? py.y : 0.0f), dlam};
-          const v3x2 dth = iinv_s2<ISO>(ic, Wc, cross2(rc, Pimp));
+          const v3x2 dth = iinv_s2<ISO, AXI>(ic, Wc, cross2(rc, Pimp));
           const v3 P0 = lo3(Pimp), P1 = hi3(Pimp), dth0 = lo3(dth), dth1 = hi3(dth);
           cd_p = sel3(act0, scale(P0, ic.inv_mass), cd_p);
           cd_th = sel3(act0, dth0, cd_th);
@@ -946,7 +994,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           v3 pos = mk3(ctr.x, ctr.y, ctr.z - h);
           v3 rc = mk3(off.x, off.y, off.z - h);
           v3 cn = crossz(rc);
-          v3 icn = iinv_z0<ISO>(ic, Wc, cn);
+          v3 icn = iinv_z0<ISO, AXI>(ic, Wc, cn);
           float wn = ic.inv_mass + dot_az0(cn, icn);
           // (dlam and gt share one packed division below)
           v3 rl = add(col_pos[j], irot_z(-h, r));
@@ -955,7 +1003,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           dx.z = 0.0f;
           float ct2 = ffma(dx.x, dx.x, dx.y * dx.y);
           v3 cnt = cross_bz0(rc, dx);
-          v3 icnt = iinv<ISO>(ic, Wc, cnt);
+          v3 icnt = iinv<ISO, AXI>(ic, Wc, cnt);
           float dent = ffma(ic.inv_mass, ct2, dot(cnt, icnt));
           const f2 q_ng = div2_pos_(mk2(pen, ct2), mk2(wn, dent + 1e-20f));
           float dlam = q_ng.x * coll_scale;
@@ -965,7 +1013,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           const bool stick = (ct2 * gt) * gt < lim * lim;
           Pimp.x = stick ? (-gt) * dx.x : 0.0f;
           Pimp.y = stick ? (-gt) * dx.y : 0.0f;
-          const v3 dth = iinv<ISO>(ic, Wc, cross(rc, Pimp));
+          const v3 dth = iinv<ISO, AXI>(ic, Wc, cross(rc, Pimp));
           // (the first collider adds to exact zeros: skipped)
           v3 ncd_p = j == 0 ? scale(Pimp, ic.inv_mass) : axpy(ic.inv_mass, Pimp, cd_p);
           v3 ncd_th = j == 0 ? dth : add(cd_th, dth);
@@ -989,7 +1037,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         w = mk3(dq.x * s, dq.y * s, dq.z * s);
       }
       // ---- (6) collisions.resolve_velocity --------------------------------------------------------------
-      const WInert<ISO> Wc = world_inertia<ISO, DIAG>(ic, r);
+      const WInert<ISO> Wc = world_inertia<ISO, DIAG, AXI>(ic, r);
 #pragma unroll
       for (int j = 0; j < MAXCOL; ++j) {
         v3 rc = sub(con_pos[j], p);
@@ -1004,7 +1052,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         float inv = div_(1.0f, vtn + 1e-10f);
         v3 dir = mk3(vt.x * inv, vt.y * inv, 0.0f);
         v3 cn = crossz(rc), cdv = cross_bz0(rc, dir);
-        v3 icn = iinv_z0<ISO>(ic, Wc, cn), icd = iinv<ISO>(ic, Wc, cdv);
+        v3 icn = iinv_z0<ISO, AXI>(ic, Wc, cn), icd = iinv<ISO, AXI>(ic, Wc, cdv);
         float wn = ic.inv_mass + dot_az0(cn, icn), wt = ic.inv_mass + dot(cdv, icd);
         float rest = -elast * vn_prev;
         float dvn = fmin_(rest, 0.0f) - vn;
@@ -1014,7 +1062,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         float jn = q_nt.x, jt = -q_nt.y;
         v3 Pimp = mk3(dir.x * jt, dir.y * jt, jn);
         v3 nv = axpy(ic.inv_mass, Pimp, v);
-        v3 nw = add(w, iinv<ISO>(ic, Wc, cross(rc, Pimp)));
+        v3 nw = add(w, iinv<ISO, AXI>(ic, Wc, cross(rc, Pimp)));
         v = sel3(con_act[j], nv, v);
         w = sel3(con_act[j], nw, w);
       }

@@ -47,7 +47,33 @@ typedef struct {
   real W[6];     /* world-frame inverse inertia R Ib R^T (xx yy zz xy xz yz), see inert_refresh() */
   int iso;       /* model-wide: inverse inertia is ib[0] * identity */
   int world;     /* the static world: everything is zero */
+  int axi;       /* model-wide: every tensor is axisymmetric about a link axis, see model_axisym() */
+  real axa, axc; /* axi: Ib = axa Id + (axc - axa) u u^T */
+  real u[3];     /* axi: the symmetry axis in the link frame */
+  real Z[3];     /* axi: the world-frame symmetry axis R u, see inert_refresh() */
 } inert_t;
+
+/* Axisymmetric models (every body-frame inverse inertia is diagonal with two equal entries: capsules — hopper,
+ * walker2d): Ib = a Id + (c - a) u u^T, R Ib R^T = a Id + (c - a) U U^T with U = R u.  For these the contract is that
+ * closed form — only U is rebuilt per stage (sp_rot of the constant u) and the tensor is applied as
+ * a v + (c - a)(U.v) U — not the general R Ib R^T product (same mathematics, different roundings; the kernels' AXI
+ * instantiations follow it). */
+static int model_axisym(const mbd_model_t* m) {
+  if (m->iso_inertia) return 0;
+  for (int l = 0; l < m->n_links; ++l) {
+    const float* ib = m->inv_inertia[l];
+    if (ib[3] != 0.0f || ib[4] != 0.0f || ib[5] != 0.0f) return 0;
+    if (ib[0] != ib[1] && ib[1] != ib[2] && ib[0] != ib[2]) return 0;
+  }
+  return 1;
+}
+static void axi_setup(inert_t* in) { /* (a, c, u) from diag(xx, yy, zz): the odd one out is the axis */
+  const real xx = in->ib[0], yy = in->ib[1], zz = in->ib[2];
+  const int ez = xx == yy, ex = !ez && yy == zz;
+  in->axa = ez ? xx : (ex ? yy : xx);
+  in->axc = ez ? zz : (ex ? xx : yy);
+  in->u[0] = ex ? R(1) : R(0); in->u[1] = (!ez && !ex) ? R(1) : R(0); in->u[2] = ez ? R(1) : R(0);
+}
 
 /* World-frame inverse inertia of a link at orientation r: W = R Ib R^T with R = (X Y Z) the axes of r,
  * T = R Ib first, then the six unique entries of T R^T (com.inv_inertia in Brax).  Re-evaluated at the
@@ -55,6 +81,7 @@ typedef struct {
  * a stage the Jacobi solves all see that same tensor.  Isotropic models never call it. */
 static void inert_refresh(inert_t* in, const real r[4]) {
   if (in->iso || in->world) return;
+  if (in->axi) { sp_rot(in->u, r, in->Z); return; }
   real X[3], Y[3], Z[3], T[3][3];
   sp_qaxes(r, X, Y, Z);
   const real xx = in->ib[0], yy = in->ib[1], zz = in->ib[2], xy = in->ib[3], xz = in->ib[4], yz = in->ib[5];
@@ -73,6 +100,13 @@ static void inert_refresh(inert_t* in, const real r[4]) {
 static inline void iinv_apply(const inert_t* in, const real v[3], real o[3]) {
   if (in->world) { sp_set3(o, 0, 0, 0); return; }
   if (in->iso) { sp_scale3(v, in->ib[0], o); return; }
+  if (in->axi) {
+    const real kd = (in->axc - in->axa) * sp_dot3(in->Z, v);
+    real m0 = sp_fma(kd, in->Z[0], in->axa * v[0]), m1 = sp_fma(kd, in->Z[1], in->axa * v[1]);
+    real m2 = sp_fma(kd, in->Z[2], in->axa * v[2]);
+    sp_set3(o, m0, m1, m2);
+    return;
+  }
   const real* W = in->W;
   real m[3];
   m[0] = sp_fma(W[4], v[2], sp_fma(W[3], v[1], W[0] * v[0]));
@@ -147,6 +181,12 @@ static inline void cross_bz0(const real a[3], const real b[3], real o[3]) {
 static inline void iinv_apply_z0(const inert_t* in, const real v[3], real o[3]) {
   if (in->world) { sp_set3(o, 0, 0, 0); return; }
   if (in->iso) { sp_set3(o, v[0] * in->ib[0], v[1] * in->ib[0], R(0)); return; }
+  if (in->axi) {
+    const real kd = (in->axc - in->axa) * sp_fma(in->Z[0], v[0], in->Z[1] * v[1]);
+    real m0 = sp_fma(kd, in->Z[0], in->axa * v[0]), m1 = sp_fma(kd, in->Z[1], in->axa * v[1]);
+    sp_set3(o, m0, m1, kd * in->Z[2]);
+    return;
+  }
   const real* W = in->W;
   real m0 = sp_fma(W[3], v[1], W[0] * v[0]), m1 = sp_fma(W[1], v[1], W[3] * v[0]), m2 = sp_fma(W[5], v[1], W[4] * v[0]);
   sp_set3(o, m0, m1, m2);
@@ -185,10 +225,13 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
   static const xf_t WORLD_X = {{0, 0, 0}, {1, 0, 0, 0}};
   static const mo_t WORLD_XD = {{0, 0, 0}, {0, 0, 0}};
   inert_t in[MBD_MAX_LINKS + 1];
+  const int axi = model_axisym(m);
   for (int l = 0; l < L; ++l) {
     in[l].inv_mass = R(m->inv_mass[l]);
     for (int k = 0; k < 6; ++k) in[l].ib[k] = R(m->inv_inertia[l][k]);
     in[l].iso = m->iso_inertia;
+    in[l].axi = axi;
+    if (axi) axi_setup(&in[l]);
     in[l].world = 0;
     inert_refresh(&in[l], x[l].r); /* stage (1) */
   }

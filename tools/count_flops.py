@@ -21,8 +21,8 @@ INSTANCES = {
     "humanoidstandup": "16,true,false,3,5,1,-4,-6,0,false,true",
     "ant": "16,true,false,4,2,1,-2,-4,-6,false,false",
     "halfcheetah": "8,true,true,4,2,1,-3,0,0,false,false,2,true",
-    "walker2d": "8,false,true,4,2,1,-3,0,0,true,false,2,true",
-    "hopper": "4,false,true,4,2,1,0,0,0,true,false,2,true",
+    "walker2d": "8,false,true,4,2,1,-3,0,0,true,false,2,true,true",
+    "hopper": "4,false,true,4,2,1,0,0,0,true,false,2,true,true",
     "cartpole": "4,true,true,4,2,1,0,0,0,false,false,2,true",
 }
 
