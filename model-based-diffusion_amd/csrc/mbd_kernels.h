@@ -1319,8 +1319,12 @@ __global__ __launch_bounds__(kScoreThreads) void score_kernel(const float* __res
                                                               const float* __restrict__ lp_demo, int N,
                                                               float rew_xref, float temp, int std_guard,
                                                               float* __restrict__ weights,
-                                                              float* __restrict__ rew_mean_out) {
-  extern __shared__ __attribute__((aligned(16))) float lg[];  // logp0 [N]
+                                                              float* __restrict__ rew_mean_out,
+                                                              float* __restrict__ lg_global) {
+  // logp0 [N]: in LDS while it fits (every plan of the reference's sizes), in a plan-owned global scratch beyond
+  // (each thread only ever touches its own entries, so the scratch needs no synchronisation either)
+  extern __shared__ __attribute__((aligned(16))) float lg_lds[];
+  float* __restrict__ lg = lg_global ? lg_global : lg_lds;
   __shared__ float red[kScoreThreads / 64];
   const int tid = threadIdx.x;
   float part = 0.0f;
@@ -1386,7 +1390,7 @@ __global__ __launch_bounds__(kWmE * kWmG) void wmean_kernel(const float* __restr
   const int e = e_raw < HNu ? e_raw : HNu - 1;
   const float* __restrict__ col = Y0s + e;
   for (int i = threadIdx.x; i < N; i += kWmE * kWmG) wl[i] = weights[i];
-  __syncthreads();
+  __syncthreads();  // (plans of >= 4096 candidates take the row-major kernels below: N always fits here)
   float acc = 0.0f;
   int n = g;
   // the chain over n is sequential by contract, its loads are not: a thread keeps 32 rows of Y0s in flight while
@@ -1505,8 +1509,9 @@ __global__ __launch_bounds__(64) void cma_sigma_kernel(const float* __restrict__
 }
 // cem: indices of the K (<= 10) largest weights, ties towards the higher index (argsort()[::-1][:10])
 __global__ __launch_bounds__(64) void cem_select_kernel(const float* __restrict__ weights, int N, int K,
-                                                        int* __restrict__ idx_out) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];
+                                                        int* __restrict__ idx_out, float* __restrict__ wl_global) {
+  extern __shared__ __attribute__((aligned(16))) float wl_lds[];
+  float* __restrict__ wl = wl_global ? wl_global : wl_lds;  // (a lane only ever touches the indices = lane mod 64)
   const int lane = threadIdx.x;
   for (int i = lane; i < N; i += 64) wl[i] = weights[i];
   for (int k = 0; k < K; ++k) {
