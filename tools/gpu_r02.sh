@@ -24,7 +24,10 @@ if [[ " $what " == *" prof "* ]]; then
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_${c}_fetch -o r02 -- $B --steps 20 --warmup 2 > $OUT/prof_${c}_fetch.log 2>&1
     rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --kernel-trace -d $OUT/prof_${c}_write -o r02 -- $B --steps 20 --warmup 2 > $OUT/prof_${c}_write.log 2>&1
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC --kernel-trace -d $OUT/prof_${c}_wait -o r02 -- $B --steps 20 --warmup 2 > $OUT/prof_${c}_wait.log 2>&1
+    # summarise here: the databases are too big to travel back (gpurun_out is capped at 64 MiB)
+    mkdir -p $OUT/profiles
+    python $R/tools/rocprof_summary.py --out $OUT/profiles r02 --config $c $OUT/prof_${c}_stats/r02_results.db $OUT/prof_${c}_sq/r02_results.db $OUT/prof_${c}_fetch/r02_results.db $OUT/prof_${c}_write/r02_results.db $OUT/prof_${c}_wait/r02_results.db | tail -1 | cut -c1-400
+    rm -rf $OUT/prof_${c}_stats $OUT/prof_${c}_sq $OUT/prof_${c}_fetch $OUT/prof_${c}_write $OUT/prof_${c}_wait
   done
-  find $OUT -name "*.db" | head -40
 fi
 du -sh $OUT

@@ -19,9 +19,13 @@ def main():
         k = argv.index("--config")
         config = argv[k + 1]
         del argv[k:k + 2]
-    tag, stats_db, pmc_dbs = argv[0], argv[1], argv[2:]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out_dir = os.path.join(root, "profiles")
+    if "--out" in argv:  # (on the GPU box: summarise next to the databases, only the summaries travel back)
+        k = argv.index("--out")
+        out_dir = argv[k + 1]
+        del argv[k:k + 2]
+    tag, stats_db, pmc_dbs = argv[0], argv[1], argv[2:]
     os.makedirs(out_dir, exist_ok=True)
     con = sqlite3.connect(stats_db)
     rows = list(con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
