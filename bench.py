@@ -252,11 +252,16 @@ def main():
             if st["i"] < 1:  # start the next plan: YN = zeros, fresh schedule position
                 st["i"] = ND - 1
                 st["Ybar"].zero_()
-            keys = _capi.prng_split(st["rng"], 2)
+            keys = st.get("keys")
+            if keys is None:
+                keys = _capi.prng_split(st["rng"], 2)
             st["rng"], ks = keys[0], _capi.key_array(keys[1])
             i, Yb = st["i"], st["Ybar"]
             _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Yb.data_ptr(), local[0].data_ptr(),
                                                     local[1].data_ptr() if DEMO else None, stream))
+            # the next step's noise depends on its key only: generated behind this rollout (a hint; same results)
+            st["keys"] = _capi.prng_split(st["rng"], 2)
+            _capi.check(lib.mbd_plan_prefetch_noise(plan.h, _capi.key_array(st["keys"][1]), stream))
             if distributed and backend == "nccl":
                 dist.all_gather_into_tensor(gath, local)  # the ONE collective of a diffusion step (RCCL/xGMI)
                 src = gath.view(world, rows, N_local).permute(1, 0, 2).reshape(rows, N_total) if rows > 1 else \

@@ -267,6 +267,11 @@ int mbd_plan_set_state0(mbd_plan* plan, const float* state0);
 int mbd_plan_sample_rollout(mbd_plan* plan, int i, const uint32_t key_sample[2],
                             const float* d_Ybar_i, float* d_rews_local, float* d_logpd_local,
                             void* stream);
+/* Optional hint between phase 1 and phase 2: the normals of the NEXT diffusion step (jax.random.normal(Y0s_rng, ...),
+ * mbd_planner.py:104 — they depend on that step's key only) are generated on the plan's second stream while the
+ * current rollout runs; the next mbd_plan_sample_rollout uses them when its key_sample equals key_next and samples as
+ * usual otherwise.  Results are bit-identical with and without the hint.  Does nothing for small plans. */
+int mbd_plan_prefetch_noise(mbd_plan* plan, const uint32_t key_next[2], void* stream);
 /* phase 2 (mbd_planner.py:111-135): from ALL N rewards (after the all-gather) standardise, demo
  * blend, softmax, weighted mean over all N candidates (noise regenerated from the counter-based PRNG,
  * so the result is bit-identical on every rank and for every shard layout), score update.

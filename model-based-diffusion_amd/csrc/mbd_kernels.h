@@ -1239,6 +1239,53 @@ __global__ __launch_bounds__(256) void sample_kernel(uint32_t k0, uint32_t k1, i
   Y0s[e] = fclip(y, -1.0f, 1.0f);
 }
 
+// The sampler in two halves, for plans that PREFETCH the noise of the next diffusion step behind the current rollout
+// (mbd_plan_prefetch_noise): eps does not depend on the step's result, only the shift by Ybar does.
+//   noise_kernel  eps[e] = normal(key)[e] for the flat elements [e_begin, e_begin + e_count) — the threefry counters,
+//                 layouts and the ErfInv polynomial of sample_kernel
+//   shift_kernel  Y0s[e] = clip(eps[e] * sigma + Ybar[e mod HNu], -1, 1) — the same two roundings as sample_kernel
+__global__ __launch_bounds__(256) void noise_kernel(uint32_t k0, uint32_t k1, int impl, int N, int HNu,
+                                                     unsigned long long e_begin, unsigned long long e_count,
+                                                     float* __restrict__ eps) {
+  const uint64_t size = (uint64_t)N * (uint64_t)HNu;
+  const uint64_t half = (size + 1) / 2;
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (impl == 1) {
+    if (tid >= e_count) return;
+    const uint64_t e = e_begin + tid;
+    uint32_t o0, o1;
+    threefry2x32(k0, k1, (uint32_t)(e >> 32), (uint32_t)e, o0, o1);
+    eps[e] = bits_to_normal(o0 ^ o1);
+    return;
+  }
+  if (e_begin == 0 && e_count == size) {  // whole tensor, legacy layout: one thread per threefry block
+    if (tid >= half) return;
+    const uint64_t j1 = tid + half;
+    uint32_t o0, o1;
+    threefry2x32(k0, k1, (uint32_t)tid, j1 < size ? (uint32_t)j1 : 0u, o0, o1);
+    eps[tid] = bits_to_normal(o0);
+    if (j1 < size) eps[j1] = bits_to_normal(o1);
+    return;
+  }
+  if (tid >= e_count) return;
+  const uint64_t e = e_begin + tid;
+  const uint64_t j0 = e < half ? e : e - half, j1 = j0 + half;
+  uint32_t o0, o1;
+  threefry2x32(k0, k1, (uint32_t)j0, j1 < size ? (uint32_t)j1 : 0u, o0, o1);
+  eps[e] = bits_to_normal(e < half ? o0 : o1);
+}
+__global__ __launch_bounds__(256) void shift_kernel(const float* __restrict__ eps, int HNu, unsigned long long e_begin,
+                                                     unsigned long long e_count, float sigma_host,
+                                                     const float* __restrict__ sigma_dev,
+                                                     const float* __restrict__ Ybar, float* __restrict__ Y0s) {
+  const float sigma = sigma_dev ? *sigma_dev : sigma_host;
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (tid >= e_count) return;
+  const uint64_t e = e_begin + tid;
+  float y = eps[e] * sigma + Ybar[e % (uint64_t)HNu];
+  Y0s[e] = fclip(y, -1.0f, 1.0f);
+}
+
 // ---- A5: demo log-densities ------------------------------------------------------------------------------
 // HumanoidTrack.eval_xref_logpd (humanoidtrack.py:98-106): xpos [B][H][K][3], xref [K][H][3]
 __global__ __launch_bounds__(64) void logpd_track_kernel(const float* __restrict__ xpos,

@@ -39,7 +39,7 @@ EXPORTS = [
     "mbd_env_create", "mbd_env_name", "mbd_builtin_model", "mbd_env_get_model", "mbd_env_xref", "mbd_env_xref_logpd",
     "mbd_env_observe", "mbd_model_observe", "mbd_env_create_car2d", "mbd_env_create_model", "mbd_env_destroy", "mbd_env_info", "mbd_env_reset",
     "mbd_env_step", "mbd_env_rew_xref", "mbd_env_rollout", "mbd_plan_create", "mbd_plan_destroy",
-    "mbd_plan_schedule", "mbd_plan_set_state0", "mbd_plan_sample_rollout", "mbd_plan_score_update",
+    "mbd_plan_schedule", "mbd_plan_set_state0", "mbd_plan_sample_rollout", "mbd_plan_prefetch_noise", "mbd_plan_score_update",
     "mbd_plan_set_sigma", "mbd_plan_get_sigma", "mbd_plan_reverse_once", "mbd_plan_run", "mbd_plan_eval", "mbd_plan_peek", "mbd_plan_kernel_time",
     "mbd_plan_enable_timing",
 ]
@@ -93,6 +93,7 @@ def load() -> C.CDLL:
     lib.mbd_plan_schedule.argtypes = [_vp, _vp, _vp, _vp]
     lib.mbd_plan_set_state0.argtypes = [_vp, _vp]
     lib.mbd_plan_sample_rollout.argtypes = [_vp, _i, _u32p, _vp, _vp, _vp, _vp]
+    lib.mbd_plan_prefetch_noise.argtypes = [_vp, _u32p, _vp]
     lib.mbd_plan_score_update.argtypes = [_vp, _i, _u32p, _vp, _vp, _vp, _vp, _vp, _vp]
     lib.mbd_plan_set_sigma.argtypes = [_vp, _f]
     lib.mbd_plan_get_sigma.argtypes = [_vp, _fp]

@@ -229,13 +229,16 @@ def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bo
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if phase_times is not None else None
     acc = [0.0, 0.0, 0.0]
     host = HostProgress(plan.Nd - 1, dev) if (sync_every_step or progress is not None) else None
+    keys = _capi.prng_split(rng, 2, impl)  # rng, Y0s_rng = split(rng)  (mbd_planner.py:103)
     for i in range(plan.Nd - 1, 0, -1):
-        keys = _capi.prng_split(rng, 2, impl)  # rng, Y0s_rng = split(rng)  (mbd_planner.py:103)
         rng, ks = keys[0], _capi.key_array(keys[1])
         if ev:
             ev[0].record()
         _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Ybar.data_ptr(), local[0].data_ptr(),
                                                 local[1].data_ptr() if demo else None, stream))
+        keys = _capi.prng_split(rng, 2, impl)  # the next step's split: its noise is generated behind this rollout
+        if i > 1:
+            _capi.check(lib.mbd_plan_prefetch_noise(plan.h, _capi.key_array(keys[1]), stream))
         if ev:
             ev[1].record()
         allv = exchange_rewards(local, world, group)

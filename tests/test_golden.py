@@ -43,8 +43,8 @@ def test_reference_goldens_or_report_unpinned(orc):
     UNPINNED and this test says so instead of passing silently."""
     files = sorted(glob.glob(os.path.join(GOLD, "golden_*.npz")))
     if not files:
-        pytest.skip("parity unpinned: no jax+brax golden vectors (tools/dump_golden.py, see tests/golden/README.md) "
-                    "are available")
+        pytest.xfail("parity unpinned: no jax+brax golden vectors (tools/dump_golden.py, see tests/golden/README.md) "
+                     "are available — the physics is NOT held to the reference yet")
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import compare_golden
