@@ -712,3 +712,47 @@ def test_progress_callback_reads_every_step(gpu):
     assert [i for i, _ in seen] == list(range(9, 0, -1))
     assert np.array_equal(np.array([r for _, r in seen], np.float32), d2["rew_means"])
     assert np.array_equal(d1["mu_0ts"], d2["mu_0ts"]) and r1 == r2
+
+
+@pytest.mark.parametrize("impl", [1, 0])
+def test_noise_prefetch_is_bit_identical(gpu, impl, monkeypatch):
+    """mbd_plan_prefetch_noise (the next step's normals generated behind the current rollout, then only shifted) is a
+    HINT: a plan big enough to use it (humanoidrun N=2048: 1.74 M noise elements) run through mbd_plan_run — which
+    prefetches — must equal, bit for bit, the same plan stepped by hand through sample_rollout / score_update without
+    any prefetch call; and a prefetch with a key that is NOT used next must be ignored.  Both threefry layouts."""
+    monkeypatch.setenv("MBD_THREEFRY_PARTITIONABLE", str(impl))
+    import torch
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.mbd_planner import Args, Plan
+    N, H, Nd = 2048, 50, 6
+    env = get_env("humanoidrun")
+    args = Args(env_name="humanoidrun", Nsample=N, Hsample=H, Ndiffuse=Nd, temp_sample=0.1,
+                disable_recommended_params=True, not_render=True)
+    st = env.reset(gpu.prng_key(2))
+    key = gpu.prng_key(6)
+    p1 = Plan(env, args)
+    p1.set_state0(st)
+    mu1, rm1, rf1, _ = p1.run(key)
+    p1.close()
+    p2 = Plan(env, args)
+    p2.set_state0(st)
+    HNu = H * 17
+    Ybar = torch.zeros(HNu, device="cuda")
+    rng = np.asarray(key, np.uint32)
+    mus, rms = [], []
+    for i in range(Nd - 1, 0, -1):
+        keys = gpu.prng_split(rng, 2, impl)
+        rng, ks = keys[0], gpu.key_array(keys[1])
+        if i == 3:  # a prefetch for a key nobody will ask for: must be ignored
+            gpu.check(p2.lib.mbd_plan_prefetch_noise(p2.h, gpu.key_array(gpu.prng_key(12345)), None))
+        loc, out, rm = torch.zeros(N, device="cuda"), torch.zeros(HNu, device="cuda"), torch.zeros(1, device="cuda")
+        gpu.check(p2.lib.mbd_plan_sample_rollout(p2.h, i, ks, Ybar.data_ptr(), loc.data_ptr(), None, None))
+        gpu.check(p2.lib.mbd_plan_score_update(p2.h, i, ks, Ybar.data_ptr(), loc.data_ptr(), None, out.data_ptr(),
+                                               rm.data_ptr(), None))
+        torch.cuda.synchronize()
+        Ybar = out
+        mus.append(out.cpu().numpy().reshape(H, 17))
+        rms.append(rm.item())
+    assert np.array_equal(np.stack(mus), mu1) and np.array_equal(np.array(rms, np.float32), rm1)
+    assert p2.eval(mu1[-1]) == rf1
+    p2.close()
