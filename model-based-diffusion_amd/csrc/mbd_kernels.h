@@ -2,11 +2,14 @@
 // of mbd/planners/mbd_planner.py:97-135:
 //
 //   sample_kernel        A1  eps -> Y0s = clip(eps*sigma_i + Ybar_i, -1, 1)        (:103-106)
+//   noise_kernel / shift_kernel  the same in two halves: the normals of the NEXT step generated behind the current
+//                        rollout (they depend on the step's key only), then only shifted by Ybar_i
 //   rollout_kernel       A2/A3  vmap(rollout_us) of the positional rigid-body step (:109, utils.py:14-20)
 //   car2d_rollout_kernel A2/A3  the same for the in-tree car2d env                  (car2d.py:77-93)
 //   logpd_*_kernel       A5  eval_xref_logpd                                        (:118)
 //   score_kernel         A4-A6  standardise, demo blend, softmax                    (:110-127)
 //   wmean_kernel         A7-A8  einsum("n,nij->ij") + score update                  (:128-133)
+//   wmean_partial_kernel / wmean_finish_kernel  the same for plans of >= 4096 candidates (row-major reads)
 //
 // Layout of the rollout kernel (the one that matters): ONE LINK PER LANE.  A candidate occupies LPS
 // consecutive lanes of a wavefront (LPS = 16 for the 11-link humanoid, 8 for the 7-link cheetah, 4 for
