@@ -68,9 +68,15 @@ enum mbd_reward_kind {
 };
 
 enum mbd_model_flags {
-  MBD_FLAG_RESET_QUAT_RAW = 1 /* reset(): leave the noise-perturbed root quaternion un-normalised (humanoidrun.py:24-26
-                                 perturbs all 7 root coordinates; whether kinematics.forward renormalises is unverified).
-                                 Default 0: normalised.                                                          */
+  MBD_FLAG_RESET_QUAT_RAW = 1, /* reset(): leave the noise-perturbed root quaternion un-normalised (humanoidrun.py:24-26
+                                  perturbs all 7 root coordinates; whether kinematics.forward renormalises is unverified).
+                                  Default 0: normalised.                                                          */
+  MBD_FLAG_PLANAR = 2          /* the model moves in the x-z plane (every hinge about the world y axis, slides and offsets
+                                  in the plane, no free joint: hopper, walker2d, halfcheetah, cartpole) and is simulated by
+                                  the planar restatement of the same six stages — in-plane coordinates only — instead
+                                  of the general 3-D arithmetic, whose float round-off leaks 1e-5..1e-3 out of the
+                                  plane over a rollout.  Set by mbd_hip/mjcf.py when the model qualifies (planar=False
+                                  keeps the 3-D path); a specification of its own for these models. */
 };
 
 typedef struct mbd_model {

@@ -1,0 +1,446 @@
+// mbd_planar.h — the rollout kernel for PLANAR models (mbd_model_t.flags & MBD_FLAG_PLANAR: hopper, walker2d,
+// halfcheetah, cartpole): the same six stages of the positional rigid-body step as rollout_kernel (mbd_kernels.h), on
+// the in-plane coordinates only — position (x, z), orientation as the half-angle pair (w, y) of the unit quaternion
+// (w, 0, y, 0), velocity (x, z), angular velocity about y: 7 floats per link instead of 13, a rotation is a 2x2
+// product with (cos, sin) built once per stage, the inertia about y is a constant, the hinge angle comes from the
+// relative half-angle pair, an angular correction is linear in its (scalar) error.  ONE LINK PER LANE, LPS lanes per
+// candidate, parent <-> child traffic by DPP row shifts when the tree fits a family (every built-in model) and by
+// ds_bpermute otherwise, state in registers for the whole rollout — the layout of rollout_kernel.
+//
+// This is a SPECIFICATION of its own for these models (the 3-D float arithmetic is not exactly planar: the joint
+// frames are quarter turns with irrational components, a rollout leaks 1e-5..1e-3 out of the plane), selected by a
+// flag of the MODEL and shared with the CPU checker, which the tests hold it to bit for bit.
+#pragma once
+
+#include "mbd_kernels.h"
+
+namespace mbd {
+
+struct PCs { float c, s; };  // cos / sin of the FULL angle about +y
+__device__ __forceinline__ PCs pl_cs(float w, float y) {
+  const float y2 = y + y;
+  return PCs{ffma(-y2, y, 1.0f), y2 * w};
+}
+__device__ __forceinline__ void pl_rot(PCs a, float x, float z, float& ox, float& oz) {
+  ox = ffma(a.s, z, a.c * x);
+  oz = ffma(-a.s, x, a.c * z);
+}
+__device__ __forceinline__ float pl_cross(float rx, float rz, float fx, float fz) { return ffma(rz, fx, -(rx * fz)); }
+__device__ __forceinline__ void pl_rel(float Pw, float Py, float Cw, float Cy, float& wr, float& yr) {
+  wr = ffma(Pw, Cw, Py * Cy);
+  yr = ffma(Pw, Cy, -(Py * Cw));
+}
+__device__ __forceinline__ float pl_angle(float wr, float yr) {
+  const float sn = (wr + wr) * yr;
+  const float cn = ffma(-(yr + yr), yr, 1.0f);
+  return angle_unit(sn, cn);
+}
+template <bool NORMALIZE>
+__device__ __forceinline__ void pl_qupdate(float& w, float& y, float dth) {
+  const float h = 0.5f * dth;
+  float nw = ffma(-h, y, w), ny = ffma(h, w, y);
+  if constexpr (NORMALIZE) {
+    const float n2 = ffma(nw, nw, ny * ny);
+    const float e = n2 - 1.0f;
+    float inv = ffma(ffma(ffma(ffma(0.2734375f, e, -0.3125f), e, 0.375f), e, -0.5f), e, 1.0f);
+    if (__builtin_expect(fabs_(e) > 0.05f, 0)) inv = 1.0f / fsqrt(n2);
+    nw = nw * inv; ny = ny * inv;
+  }
+  w = nw; y = ny;
+}
+
+// LPS lanes per candidate; D0, D1: DPP layout (lane(parent) = lane(s-th child) + Ds; D0 = 0: ds_bpermute exchange,
+// up to kMaxChildren children); MAXCOL sphere colliders per link (0: the contact stages are compiled out)
+template <int LPS, int MAXCOL, int D0 = 0, int D1 = 0>
+__global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
+  constexpr bool DPP = D0 != 0;
+  constexpr int NSLOT = DPP ? (D1 != 0 ? 2 : 1) : kMaxChildren;
+  const mbd_model_t* __restrict__ M = P.model;
+  const int lane = threadIdx.x & 63;
+  const int base = lane & ~(LPS - 1);
+  const int l_lane = lane & (LPS - 1);
+  const int L = M->n_links;
+  const int l_link = DPP ? (int)P.lane_tab[l_lane] : l_lane;
+  const bool link_ok = l_link >= 0 && l_link < L;
+  const int l = link_ok ? l_link : 0;
+  auto lane_of = [&](int link) { return base + (DPP ? (int)P.lane_tab[16 + link] : link); };
+  const bool root_lane = link_ok && l == 0;
+  constexpr int SPW = 64 / LPS;
+  const int wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int b_raw = wave_id * SPW + lane / LPS;
+  const bool b_ok = b_raw < P.B;
+  const int b = b_ok ? b_raw : P.B - 1;
+  const int H = P.H, Nu = M->n_act, nfr = M->n_frames;
+
+  // ---- per-lane model constants (padding lanes: everything that scales a contribution is zero) ------------
+  const int parent = M->parent[l];
+  const bool world_parent = parent < 0;
+  const int plane = (link_ok && parent >= 0) ? lane_of(parent) : lane;
+  const int nr = link_ok ? M->n_rot[l] : 0, ns = link_ok ? M->n_slide[l] : 0;
+  const float im_c = link_ok ? M->inv_mass[l] : 0.0f, iy_c = link_ok ? M->inv_inertia[l][1] : 0.0f;
+  const float im_p = (link_ok && !world_parent) ? M->inv_mass[parent] : 0.0f;
+  const float iy_p = (link_ok && !world_parent) ? M->inv_inertia[parent][1] : 0.0f;
+  const float invm_sum = im_p + im_c;
+  const float apx = M->ap_pos[l][0], apz = M->ap_pos[l][2], acx = M->ac_pos[l][0], acz = M->ac_pos[l][2];
+  const float sg = (M->ap_rot[l][0] * M->ap_rot[l][3] < 0.0f) ? -1.0f : 1.0f;
+  const float wpar = world_parent ? 1.0f : 0.0f;  // the world's orientation (1, 0): added to the fetched zero
+  float sx[2], sz[2], sl_lo[2], sl_hi[2], sl_damp[2];
+  {
+    const q4 aprot = q4{M->ap_rot[l][0], M->ap_rot[l][1], M->ap_rot[l][2], M->ap_rot[l][3]};
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const bool has = link_ok && j < ns;
+      const v3 s = rot(mk3(M->slide_axis[l][j][0], M->slide_axis[l][j][1], M->slide_axis[l][j][2]), aprot);
+      sx[j] = has ? s.x : 0.0f; sz[j] = has ? s.z : 0.0f;
+      sl_lo[j] = has ? M->slide_lo[l][j] : -1e9f; sl_hi[j] = has ? M->slide_hi[l][j] : 1e9f;
+      sl_damp[j] = M->slide_damp[l][j];
+    }
+  }
+  const float lim_lo = M->rot_lo[l][0], lim_hi = M->rot_hi[l][0];
+  const float stiff = M->rot_stiff[l][0], damp = M->rot_damp[l][0];
+  const float ang_damp = link_ok ? M->ang_damp[l] : 0.0f, vel_damp = link_ok ? M->vel_damp[l] : 0.0f;
+  const float js_pos = link_ok ? M->joint_scale_pos : 0.0f, js_ang = M->joint_scale_ang;
+  float kc = 0.0f, kp = 0.0f;
+  if (link_ok) { kc = (iy_c / (iy_p + iy_c)) * js_ang; kp = (iy_p / (iy_p + iy_c)) * js_ang; }
+  int act_rot = -1, act_sl[2] = {-1, -1};
+  float gear_rot = 0.0f, alo_rot = 0.0f, ahi_rot = 0.0f, gear_sl[2] = {0.0f, 0.0f}, alo_sl[2] = {0.0f, 0.0f}, ahi_sl[2] = {0.0f, 0.0f};
+  for (int a = 0; a < Nu; ++a) {
+    if (M->act_link[a] != l || !link_ok) continue;
+    const int s = M->act_slot[a];
+    if (s == 0) { act_rot = a; gear_rot = M->act_gear[a]; alo_rot = M->act_lo[a]; ahi_rot = M->act_hi[a]; }
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      if (s == 3 + j) { act_sl[j] = a; gear_sl[j] = M->act_gear[a]; alo_sl[j] = M->act_lo[a]; ahi_sl[j] = M->act_hi[a]; }
+  }
+  // children: DPP masks (rm[s]: this link has an s-th child at lane - Ds; pm[s]: this link is the s-th child of its
+  // parent at lane + Ds) or source lanes of the shuffle exchange (a missing child: own lane, masked)
+  float rm[2] = {0.0f, 0.0f}, pm[2] = {0.0f, 0.0f};
+  int child_src[NSLOT];
+  float child_m[NSLOT];
+  {
+    int nc = 0;
+#pragma unroll
+    for (int c = 0; c < NSLOT; ++c) { child_src[c] = lane; child_m[c] = 0.0f; }
+    for (int c = l + 1; c < L; ++c)
+      if (M->parent[c] == l && link_ok) {
+#pragma unroll
+        for (int j = 0; j < NSLOT; ++j)
+          if (j == nc) { child_src[j] = lane_of(c); child_m[j] = 1.0f; }
+        ++nc;
+      }
+    if constexpr (DPP) {
+      int myslot = -1;
+      if (link_ok && parent >= 0) {
+        myslot = 0;
+        for (int c = 0; c < l; ++c) myslot += M->parent[c] == parent ? 1 : 0;
+      }
+#pragma unroll
+      for (int k = 0; k < 2; ++k) { rm[k] = (k < NSLOT && child_m[k < NSLOT ? k : 0] != 0.0f) ? 1.0f : 0.0f; pm[k] = myslot == k ? 1.0f : 0.0f; }
+    }
+  }
+  float colx[MAXCOL > 0 ? MAXCOL : 1], colz[MAXCOL > 0 ? MAXCOL : 1], col_rad[MAXCOL > 0 ? MAXCOL : 1];
+  bool col_has[MAXCOL > 0 ? MAXCOL : 1];
+  if constexpr (MAXCOL > 0) {
+    int nc = 0;
+#pragma unroll
+    for (int j = 0; j < MAXCOL; ++j) { col_has[j] = false; col_rad[j] = 0.0f; colx[j] = colz[j] = 0.0f; }
+    for (int k = 0; k < M->n_col; ++k)
+      if (M->col_link[k] == l && link_ok) {
+#pragma unroll
+        for (int j = 0; j < MAXCOL; ++j)
+          if (j == nc) { col_has[j] = true; col_rad[j] = M->col_radius[k]; colx[j] = M->col_pos[k][0]; colz[j] = M->col_pos[k][2]; }
+        ++nc;
+      }
+  }
+  const float comx = M->com[l][0], comz = M->com[l][2];
+  const float dt = M->dt, inv_dt = 1.0f / M->dt, vel_fac = M->vel_fac, ang_fac = M->ang_fac;
+  const float two_inv_dt = 2.0f * inv_dt;
+  const float coll_scale = M->collide_scale, mu = M->friction, elast = M->elasticity;
+  const float gx = link_ok ? M->gravity[0] : 0.0f, gz = link_ok ? M->gravity[2] : 0.0f;
+  const int rkind = M->reward_kind;
+  const float rp0 = M->reward_params[0], rp1 = M->reward_params[1];
+  const float dt_ctrl = M->dt * (float)nfr;
+
+  // ---- exchange -----------------------------------------------------------------------------------------
+  auto from_parent = [&](float v) -> float {  // the value of v in the parent's lane (0 for a world parent)
+    if constexpr (DPP) {
+      float o = dpp_from<D0>(v) * pm[0];
+      if constexpr (D1 != 0) o = ffma(dpp_from<D1>(v), pm[1], o);
+      return o;
+    } else {
+      const float o = shfl(v, plane);
+      return world_parent ? 0.0f : o;
+    }
+  };
+  auto add_children = [&](float own, float contrib) -> float {  // own + child 0 + child 1 + ..., in child order
+    if constexpr (DPP) {
+      float o = ffma(dpp_from<-D0>(contrib), rm[0], own);
+      if constexpr (D1 != 0) o = ffma(dpp_from<-D1>(contrib), rm[1], o);
+      return o;
+    } else {
+      float o = own;
+#pragma unroll
+      for (int c = 0; c < NSLOT; ++c) {
+        if (c < P.max_children) o = ffma(shfl(contrib, child_src[c]), child_m[c], o);
+      }
+      return o;
+    }
+  };
+
+  // ---- state -------------------------------------------------------------------------------------------
+  const float* s0 = P.state0 + l * MBD_LINK_STATE;
+  float px = s0[0], pz = s0[2], qw = s0[3], qy = s0[5], vx = s0[7], vz = s0[9], om = s0[11];
+  if (!link_ok) { px = pz = 0.0f; qw = 1.0f; qy = 0.0f; vx = vz = om = 0.0f; }
+
+  const float* u_row = P.us + (size_t)b * H * Nu;
+  auto load_u = [&](int t, int a) { return u_row[(size_t)t * Nu + (a >= 0 ? a : 0)]; };
+  float u_rot = load_u(0, act_rot), u_sl0 = load_u(0, act_sl[0]), u_sl1 = load_u(0, act_sl[1]);
+  float rew_sum = 0.0f;
+
+  for (int t = 0; t < H; ++t) {
+    const float tau0 = fclip(act_rot >= 0 ? u_rot : 0.0f, alo_rot, ahi_rot) * gear_rot;
+    float tau_sl[2];
+    tau_sl[0] = fclip(act_sl[0] >= 0 ? u_sl0 : 0.0f, alo_sl[0], ahi_sl[0]) * gear_sl[0];
+    tau_sl[1] = fclip(act_sl[1] >= 0 ? u_sl1 : 0.0f, alo_sl[1], ahi_sl[1]) * gear_sl[1];
+    float ctrl_cost = 0.0f;
+    if (rkind == MBD_REW_HALFCHEETAH && root_lane) {
+      for (int a = 0; a < Nu; ++a) {
+        const float ua = u_row[(size_t)t * Nu + a];
+        ctrl_cost = ctrl_cost + ua * ua;
+      }
+    }
+    const int tn = t + 1 < H ? t + 1 : t;  // the next control step's actions, in flight across the substeps
+    const float un_rot = load_u(tn, act_rot), un_sl0 = load_u(tn, act_sl[0]), un_sl1 = load_u(tn, act_sl[1]);
+    __builtin_amdgcn_sched_barrier(0);
+    float o0x, o0z;
+    {
+      float tx, tz;
+      pl_rot(pl_cs(qw, qy), comx, comz, tx, tz);
+      o0x = px - tx; o0z = pz - tz;
+    }
+    (void)o0z;
+
+    for (int fr = 0; fr < nfr; ++fr) {
+      // ---- (1) joints.acceleration_update ----------------------------------------------------------------
+      float Ppx = from_parent(px), Ppz = from_parent(pz), Pw = from_parent(qw) + wpar, Py = from_parent(qy);
+      const float Pvx = from_parent(vx), Pvz = from_parent(vz), Pom = from_parent(om);
+      float fcvx, fcvz, fcw, fpvx, fpvz, fpw;
+      {
+        const PCs cP = pl_cs(Pw, Py), cC = pl_cs(qw, qy);
+        float rpx, rpz, rcx, rcz;
+        pl_rot(cP, apx, apz, rpx, rpz);
+        pl_rot(cC, acx, acz, rcx, rcz);
+        const float vpx = ffma(Pom, rpz, Pvx), vpz = ffma(-Pom, rpx, Pvz);
+        const float vcx = ffma(om, rcz, vx), vcz = ffma(-om, rcx, vz);
+        float rvx = vcx - vpx, rvz = vcz - vpz;
+        const float rw = om - Pom;
+        float wr, yr;
+        pl_rel(Pw, Py, qw, qy, wr, yr);
+        const float ang = sg * pl_angle(wr, yr);
+        const float qd = sg * rw;
+        float fk = ffma(-stiff, ang, ffma(-damp, qd, tau0));
+        fk = nr >= 1 ? fk : 0.0f;
+        const float Ty = ffma(-ang_damp, rw, fk * sg);
+        float Fx = 0.0f, Fz = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float vs = ffma(rvx, sx[j], rvz * sz[j]);
+          const float fs = j < ns ? ffma(-sl_damp[j], vs, tau_sl[j]) : 0.0f;
+          Fx = ffma(fs, sx[j], Fx); Fz = ffma(fs, sz[j], Fz);
+          rvx = ffma(-vs, sx[j], rvx); rvz = ffma(-vs, sz[j], rvz);
+        }
+        Fx = ffma(-vel_damp, rvx, Fx); Fz = ffma(-vel_damp, rvz, Fz);
+        fcvx = Fx * im_c; fcvz = Fz * im_c;
+        fcw = (Ty + pl_cross(rcx, rcz, Fx, Fz)) * iy_c;
+        fpvx = Fx * (-im_p); fpvz = Fz * (-im_p);
+        fpw = -((Ty + pl_cross(rpx, rpz, Fx, Fz)) * iy_p);
+      }
+      // ---- (2) integrator.integrate_xdd ---------------------------------------------------------------------
+      {
+        const float ax = add_children(fcvx, fpvx), az = add_children(fcvz, fpvz), aw = add_children(fcw, fpw);
+        vx = ffma(ax + gx, dt, vel_fac * vx);
+        vz = ffma(az + gz, dt, vel_fac * vz);
+        om = ffma(aw, dt, ang_fac * om);
+      }
+      const float pxp = px, pzp = pz, qwp = qw, qyp = qy;
+      px = ffma(vx, dt, px);
+      pz = ffma(vz, dt, pz);
+      pl_qupdate<true>(qw, qy, om * dt);
+      // ---- (3) joints.position_update (Jacobi) ---------------------------------------------------------------
+      Ppx = from_parent(px); Ppz = from_parent(pz); Pw = from_parent(qw) + wpar; Py = from_parent(qy);
+      float dcx, dcz, dcth, dpx, dpz, dpth;
+      {
+        const PCs cP = pl_cs(Pw, Py), cC = pl_cs(qw, qy);
+        float rpx, rpz, rcx, rcz;
+        pl_rot(cP, apx, apz, rpx, rpz);
+        pl_rot(cC, acx, acz, rcx, rcz);
+        const float apwx = Ppx + rpx, apwz = Ppz + rpz, acwx = px + rcx, acwz = pz + rcz;
+        float dx = apwx - acwx, dz = apwz - acwz;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const float cf = -ffma(dx, sx[j], dz * sz[j]);
+          dx = ffma(cf, sx[j], dx); dz = ffma(cf, sz[j], dz);
+        }
+        const float c2 = ffma(dx, dx, dz * dz);
+        const float crp = pl_cross(rpx, rpz, dx, dz), crc = pl_cross(rcx, rcz, dx, dz);
+        const float wq = crp * (iy_p * crp) + crc * (iy_c * crc);
+        const float den = ffma(invm_sum, c2, wq) + 1e-20f;
+        const float g = div_pos_(c2, den) * js_pos;
+        const float Px = dx * g, Pz = dz * g;
+        dcx = Px * im_c; dcz = Pz * im_c;
+        dpx = Px * (-im_p); dpz = Pz * (-im_p);
+        dcth = pl_cross(rcx, rcz, Px, Pz) * iy_c;
+        dpth = -(pl_cross(rpx, rpz, Px, Pz) * iy_p);
+        if (P.slide_limits) {  // (wave-uniform)
+          const float ex = acwx - apwx, ez = acwz - apwz;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const float qs = ffma(ex, sx[j], ez * sz[j]);
+            const float viol = qs - fclip(qs, sl_lo[j], sl_hi[j]);
+            const float lx = sx[j] * (-viol), lz = sz[j] * (-viol);
+            const float l2 = ffma(lx, lx, lz * lz);
+            const float lp = pl_cross(rpx, rpz, lx, lz), lc = pl_cross(rcx, rcz, lx, lz);
+            const float dens = ffma(invm_sum, l2, lp * (iy_p * lp) + lc * (iy_c * lc));
+            const float gs = div_pos_(l2, dens + 1e-20f) * js_pos;
+            const float Sx = lx * gs, Sz = lz * gs;
+            dcx = ffma(Sx, im_c, dcx); dcz = ffma(Sz, im_c, dcz);
+            dpx = ffma(Sx, -im_p, dpx); dpz = ffma(Sz, -im_p, dpz);
+            dcth = ffma(pl_cross(rcx, rcz, Sx, Sz), iy_c, dcth);
+            dpth = ffma(pl_cross(rpx, rpz, Sx, Sz), -iy_p, dpth);
+          }
+        }
+        float wr, yr;
+        pl_rel(Pw, Py, qw, qy, wr, yr);
+        const float ang = sg * pl_angle(wr, yr);
+        const float viol = ang - fclip(ang, lim_lo, lim_hi);
+        const float E_hinge = (-viol) * sg;
+        const float E_weld = (wr < 0.0f ? -2.0f : 2.0f) * (-yr);
+        const float E = nr < 1 ? E_weld : E_hinge;
+        dcth = ffma(kc, E, dcth);
+        dpth = ffma(-kp, E, dpth);
+      }
+      {
+        const float ax = add_children(dcx, dpx), az = add_children(dcz, dpz), ath = add_children(dcth, dpth);
+        px = px + ax; pz = pz + az;
+        pl_qupdate<false>(qw, qy, ath);  // renormalised at the end of stage (4)
+      }
+      // ---- (4) sphere-plane contacts + collisions.resolve_position -----------------------------------------
+      float cposx[MAXCOL > 0 ? MAXCOL : 1], cposz[MAXCOL > 0 ? MAXCOL : 1], cdlam[MAXCOL > 0 ? MAXCOL : 1];
+      bool cact[MAXCOL > 0 ? MAXCOL : 1];
+      {
+        float cdx = 0.0f, cdz = 0.0f, cdth = 0.0f;
+        if constexpr (MAXCOL > 0) {
+          const PCs a = pl_cs(qw, qy), ap = pl_cs(qwp, qyp);
+#pragma unroll
+          for (int j = 0; j < MAXCOL; ++j) {
+            float offx, offz;
+            pl_rot(a, colx[j], colz[j], offx, offz);
+            const float ctrx = px + offx, ctrz = pz + offz;
+            const float pen = col_rad[j] - ctrz;
+            const bool active = col_has[j] && pen > 0.0f;
+            const float h = ffma(-0.5f, pen, col_rad[j]);
+            const float posx = ctrx, posz = ctrz - h;
+            const float rcx = offx, rcz = offz - h;
+            const float icn = rcx * iy_c;
+            const float wn = ffma(icn, rcx, im_c);
+            const float d = -h;
+            const float rlx = ffma(-a.s, d, colx[j]), rlz = ffma(a.c, d, colz[j]);
+            const float pprevx = pxp + ffma(ap.s, rlz, ap.c * rlx);
+            const float ddx = posx - pprevx;
+            const float ct2 = ddx * ddx;
+            const float cnt = rcz * ddx;
+            const float dent = ffma(im_c, ct2, cnt * (cnt * iy_c));
+            const f2 q_ng = div2_pos_(mk2(pen, ct2), mk2(wn, dent + 1e-20f));
+            const float dlam = q_ng.x * coll_scale, gt = q_ng.y;
+            const float lim = mu * dlam;
+            const float Pix = ((ct2 * gt) * gt < lim * lim) ? (-gt) * ddx : 0.0f, Piz = dlam;
+            const float dth = pl_cross(rcx, rcz, Pix, Piz) * iy_c;
+            cdx = active ? ffma(im_c, Pix, cdx) : cdx;
+            cdz = active ? ffma(im_c, Piz, cdz) : cdz;
+            cdth = active ? cdth + dth : cdth;
+            cposx[j] = posx; cposz[j] = posz; cdlam[j] = dlam; cact[j] = active;
+          }
+        }
+        px = px + cdx; pz = pz + cdz;
+        pl_qupdate<true>(qw, qy, cdth);
+      }
+      // ---- (5) integrator.project_xd -----------------------------------------------------------------------
+      const float vz_old = vz, om_old = om;
+      vx = (px - pxp) * inv_dt;
+      vz = (pz - pzp) * inv_dt;
+      {
+        const float dqw = ffma(qw, qwp, qy * qyp);
+        const float dqy = ffma(qy, qwp, -(qw * qyp));
+        om = dqy * (dqw < 0.0f ? -two_inv_dt : two_inv_dt);
+      }
+      // ---- (6) collisions.resolve_velocity (sequential per link) ---------------------------------------------
+      if constexpr (MAXCOL > 0) {
+#pragma unroll
+        for (int j = 0; j < MAXCOL; ++j) {
+          const float rcx = cposx[j] - px, rcz = cposz[j] - pz;
+          const float vptx = ffma(om, rcz, vx), vptz = ffma(-om, rcx, vz);
+          float vn_prev = 0.0f;
+          if (elast != 0.0f) vn_prev = ffma(-om_old, rcx, vz_old);  // (wave-uniform; with e = 0 the term is exactly 0)
+          const float vtn = fabs_(vptx);
+          const float inv = div_(1.0f, vtn + 1e-10f);
+          const float dir = vptx * inv;
+          const float icn = rcx * iy_c;
+          const float wn = ffma(icn, rcx, im_c);
+          const float cdv = rcz * dir;
+          const float wt = ffma(cdv, cdv * iy_c, im_c);
+          const float rest = -elast * vn_prev;
+          const float dvn = fmin_(rest, 0.0f) - vptz;
+          const float jt_max = (mu * cdlam[j]) * inv_dt;
+          const float dvt = fmin_(jt_max * wt, vtn);
+          const f2 q_nt = div2_sp_(mk2(dvn, dvt), mk2(wn, wt));
+          const float jn = q_nt.x, jt = -q_nt.y;
+          const float Pix = dir * jt, Piz = jn;
+          const float nvx = ffma(im_c, Pix, vx), nvz = ffma(im_c, Piz, vz);
+          const float nom = om + pl_cross(rcx, rcz, Pix, Piz) * iy_c;
+          vx = cact[j] ? nvx : vx; vz = cact[j] ? nvz : vz; om = cact[j] ? nom : om;
+        }
+      }
+    }  // substeps
+
+    // ---- reward ------------------------------------------------------------------------------------------------
+    float o1x, o1z;
+    {
+      float tx, tz;
+      pl_rot(pl_cs(qw, qy), comx, comz, tx, tz);
+      o1x = px - tx; o1z = pz - tz;
+    }
+    float cart_cos = 0.0f, cart_vs = 0.0f;
+    if (rkind == MBD_REW_CARTPOLE) {  // cartpole.py:45: cos(q[1]) - |qd[0]| (wave-uniform branch)
+      const float Pw = from_parent(qw) + wpar, Py = from_parent(qy);
+      float wr, yr, sn, cs;
+      pl_rel(Pw, Py, qw, qy, wr, yr);
+      sincos_(sg * pl_angle(wr, yr), &sn, &cs);     // link 1's hinge angle (meaningful on link 1's lane)
+      float rx, rz;
+      pl_rot(pl_cs(qw, qy), acx, acz, rx, rz);
+      const float vcx = ffma(om, rz, vx), vcz = ffma(-om, rx, vz);
+      cart_vs = ffma(vcx, sx[0], vcz * sz[0]);     // own slide-0 velocity: used on link 0's lane
+      cart_cos = shfl(cs, lane_of(1));
+    }
+    if (root_lane) {
+      float rew;
+      if (rkind == MBD_REW_HOPPER) {
+        rew = o1x - fclip(fabs_(o1z - rp0), -1.0f, 1.0f) * rp1;
+      } else if (rkind == MBD_REW_HALFCHEETAH) {
+        rew = rp0 * ((o1x - o0x) / dt_ctrl) - rp1 * ctrl_cost;
+      } else {
+        rew = cart_cos - fabs_(cart_vs);
+      }
+      rew_sum = rew_sum + rew;
+      if (b_ok && P.rewss) P.rewss[(size_t)b * H + t] = rew;
+    }
+    u_rot = un_rot; u_sl0 = un_sl0; u_sl1 = un_sl1;
+  }  // control steps
+  if (root_lane && b_ok && P.rews) P.rews[b] = rew_sum / (float)H;
+  if (P.state_final && link_ok && b_ok) {
+    float* o = P.state_final + ((size_t)b * L + l) * MBD_LINK_STATE;
+    o[0] = px; o[1] = 0.0f; o[2] = pz; o[3] = qw; o[4] = 0.0f; o[5] = qy; o[6] = 0.0f;
+    o[7] = vx; o[8] = 0.0f; o[9] = vz; o[10] = 0.0f; o[11] = om; o[12] = 0.0f;
+  }
+}
+
+}  // namespace mbd

@@ -230,11 +230,48 @@ def _fuse(b: _Body) -> None:
     b.children = new_children
 
 
+def is_planar(F) -> bool:
+    """A model the planar restatement applies to (MBD_FLAG_PLANAR, include/mbd_hip.h): every joint is a hinge about the
+    world y axis (joint frames = a quarter turn about z, identical on both sides) or hinge-less, slides only on
+    world-parented links and in the x-z plane, link frames un-rotated, all offsets in the plane, diagonal inertia, no
+    gravity along y, at most two slide dofs."""
+    L = int(F["n_links"])
+    if L < 1 or abs(float(np.asarray(F["gravity"])[1])) != 0.0:
+        return False
+    for l in range(L):
+        nr, ns = int(F["n_rot"][l]), int(F["n_slide"][l])
+        if nr < 0 or nr > 1 or ns > 2 or (ns > 0 and int(F["parent"][l]) >= 0):
+            return False
+        apr, acr = np.asarray(F["ap_rot"][l], np.float64), np.asarray(F["ac_rot"][l], np.float64)
+        if not np.array_equal(apr, acr) or apr[1] != 0.0 or apr[2] != 0.0:
+            return False
+        if nr == 1 and abs(abs(2.0 * apr[0] * apr[3]) - 1.0) > 1e-6:   # joint X axis = +-y
+            return False
+        if nr == 0 and not np.array_equal(apr, [1.0, 0.0, 0.0, 0.0]):
+            return False
+        if not np.array_equal(np.asarray(F["link_rot"][l], np.float64), [1.0, 0.0, 0.0, 0.0]):
+            return False
+        for key in ("ap_pos", "ac_pos", "com"):
+            if float(np.asarray(F[key][l])[1]) != 0.0:
+                return False
+        if np.any(np.asarray(F["inv_inertia"][l])[3:] != 0.0):
+            return False
+        for k in range(ns):
+            s_w = _rot(np.asarray(F["slide_axis"][l][k], np.float64), apr)
+            if abs(s_w[1]) > 1e-9:
+                return False
+    ncol = int(np.asarray(F["col_link"]).shape[0]) if np.ndim(F["col_link"]) else 0
+    for k in range(ncol):
+        if float(np.asarray(F["col_pos"])[k][1]) != 0.0:
+            return False
+    return int(np.asarray(F["track_link"]).size) == 0
+
+
 def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Optional[str] = None,
          track_names: Sequence[str] = (), reset_noise: float = 0.0,
          reward_params: Sequence[float] = (), dt_override: Optional[float] = None,
          init_q_offset: Sequence[float] = (), gear_override: Sequence[float] = (),
-         passive_joint_forces: bool = True, reset_quat_raw: bool = False) -> Model:
+         passive_joint_forces: bool = True, reset_quat_raw: bool = False, planar: Optional[bool] = None) -> Model:
     """Compile an MJCF file. ``n_frames`` is the env's physics substeps per control step
     (humanoidrun.py:17 -> 7, humanoidtrack.py:46 -> 5, hopper.py:18 -> 20).
 
@@ -245,6 +282,8 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
       reset_quat_raw        reset() leaves the noise-perturbed root quaternion un-normalised
                             (MBD_FLAG_RESET_QUAT_RAW; default False: normalised).
       gear_override         the env class's replacement of sys.actuator.gear (brax ant / half_cheetah).
+      planar                None: set MBD_FLAG_PLANAR when the model qualifies (see ``is_planar``); False: keep
+                            the general 3-D arithmetic for a planar model.
     Reward-side switches live in reward_params (ant: [5] = terminate_when_unhealthy)."""
     root = ET.parse(path).getroot()
     comp = root.find("compiler")
@@ -481,7 +520,7 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
     F.update(
         n_links=L, n_q=nq, n_qd=nqd, n_act=len(act_link), n_col=len(col_link), n_track=len(track),
         n_frames=int(n_frames), reward_kind=REWARD_KINDS.get(env_name, 0), iso_inertia=int(iso),
-        flags=int(1 if reset_quat_raw else 0),
+        flags=int(1 if reset_quat_raw else 0),  # (MBD_FLAG_PLANAR is added below, once the model is complete)
         dt=np.float32(dt), vel_fac=np.float32(math.exp(custom["vel_damping"] * dt)),
         ang_fac=np.float32(math.exp(custom["ang_damping"] * dt)),
         joint_scale_pos=np.float32(custom["joint_scale_pos"]),
@@ -502,6 +541,12 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
     for k in ("dt", "vel_fac", "ang_fac", "joint_scale_pos", "joint_scale_ang", "collide_scale",
               "friction", "elasticity", "reset_noise"):
         F[k] = float(F[k])
+    if planar is None or planar:
+        ok = is_planar(F)
+        if planar and not ok:
+            raise ValueError("planar=True but the model does not move in the x-z plane")
+        if ok:
+            F["flags"] = int(F["flags"]) | 2  # MBD_FLAG_PLANAR
     model = Model(F, names, act_names, env_name)
     model.masses = np.array([ent["mass"] for ent in links])      # diagnostics / tests only
     model.inertias = np.stack([ent["inertia"] for ent in links])

@@ -198,6 +198,28 @@ typedef struct {
   real dlam;   /* normal lambda of the positional solve */
 } contact_t;
 
+#include "mbd_oracle_planar.h"
+
+static void to_planar(int L, const xf_t* x, const mo_t* xd, pxf_t* px, pmo_t* pd) {
+  for (int l = 0; l < L; ++l) {
+    px[l].px = x[l].p[0]; px[l].pz = x[l].p[2]; px[l].qw = x[l].r[0]; px[l].qy = x[l].r[2];
+    pd[l].vx = xd[l].v[0]; pd[l].vz = xd[l].v[2]; pd[l].om = xd[l].w[1];
+  }
+}
+static void pl_origin3(const mbd_model_t* m, int l, const xf_t* x, real o[3]) { /* x.pos of a planar model's link */
+  real tx, tz;
+  pl_rot(pl_cs(x[l].r[0], x[l].r[2]), R(m->com[l][0]), R(m->com[l][2]), &tx, &tz);
+  o[0] = x[l].p[0] - tx; o[1] = R(0); o[2] = x[l].p[2] - tz;
+}
+static void from_planar(int L, const pxf_t* px, const pmo_t* pd, xf_t* x, mo_t* xd) {
+  for (int l = 0; l < L; ++l) {
+    x[l].p[0] = px[l].px; x[l].p[1] = R(0); x[l].p[2] = px[l].pz;
+    x[l].r[0] = px[l].qw; x[l].r[1] = R(0); x[l].r[2] = px[l].qy; x[l].r[3] = R(0);
+    xd[l].v[0] = pd[l].vx; xd[l].v[1] = R(0); xd[l].v[2] = pd[l].vz;
+    xd[l].w[0] = R(0); xd[l].w[1] = pd[l].om; xd[l].w[2] = R(0);
+  }
+}
+
 /* ------------------------------------------------------------------------------------------------ */
 /* one physics substep (brax/positional/pipeline.py::step)                                           */
 /* ------------------------------------------------------------------------------------------------ */
@@ -220,6 +242,13 @@ static void dump_stage(int stage, int L, const xf_t* x, const mo_t* xd) {
 static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot /* [L][3] */,
                     const real* tau_slide /* [L][3] */) {
   const int L = m->n_links;
+  if (m->flags & MBD_FLAG_PLANAR) { /* planar models: the planar restatement (mbd_oracle_planar.h) */
+    pxf_t px[MBD_MAX_LINKS]; pmo_t pd[MBD_MAX_LINKS];
+    to_planar(L, x, xd, px, pd);
+    substep_planar(m, px, pd, tau_rot, tau_slide, g_stage_dump);
+    from_planar(L, px, pd, x, xd);
+    return;
+  }
   const real dt = R(m->dt);
   const real inv_dt = R(1) / dt;
   static const xf_t WORLD_X = {{0, 0, 0}, {1, 0, 0, 0}};
@@ -549,11 +578,12 @@ static real env_step(const mbd_model_t* m, xf_t* x, mo_t* xd, const float* actio
     if (s < 3) tau_rot[l * 3 + s] += u; else tau_slide[l * 3 + s - 3] += u;
   }
   real o0[3], v0[3];
-  link_origin(m, 0, x, o0);
-  link_origin_vel(m, 0, x, xd, v0);
+  const int planar = (m->flags & MBD_FLAG_PLANAR) != 0;
+  if (planar) { pl_origin3(m, 0, x, o0); v0[0] = v0[1] = v0[2] = R(0); }
+  else { link_origin(m, 0, x, o0); link_origin_vel(m, 0, x, xd, v0); }
   for (int f = 0; f < m->n_frames; ++f) substep(m, x, xd, tau_rot, tau_slide);
   real o1[3];
-  link_origin(m, 0, x, o1);
+  if (planar) pl_origin3(m, 0, x, o1); else link_origin(m, 0, x, o1);
   (void)L;
   switch (m->reward_kind) {
     case MBD_REW_HUMANOIDRUN: /* humanoidrun.py:46-51 */
@@ -578,6 +608,16 @@ static real env_step(const mbd_model_t* m, xf_t* x, mo_t* xd, const float* actio
       return (R(m->reward_params[0]) * ((o1[0] - o0[0]) / dtc) + healthy) - R(m->reward_params[1]) * ctrl;
     }
     case MBD_REW_CARTPOLE: { /* cartpole.py:45: cos(q[1]) - |qd[0]|: hinge angle of link 1, slide velocity of link 0 */
+      if (planar) {
+        plink_t K[MBD_MAX_LINKS];
+        pl_setup(m, K);
+        real wr, yr, sn, cs, r0x, r0z;
+        pl_rel(x[0].r[0], x[0].r[2], x[1].r[0], x[1].r[2], &wr, &yr);
+        sp_sincos(K[1].sg * pl_angle(wr, yr), &sn, &cs);
+        pl_rot(pl_cs(x[0].r[0], x[0].r[2]), K[0].acx, K[0].acz, &r0x, &r0z);
+        const real vcx = sp_fma(xd[0].w[1], r0z, xd[0].v[0]), vcz = sp_fma(-xd[0].w[1], r0x, xd[0].v[2]);
+        return cs - sp_abs(sp_fma(vcx, K[0].sx[0], vcz * K[0].sz[0]));
+      }
       static const xf_t WORLD_X = {{0, 0, 0}, {1, 0, 0, 0}};
       jf_t f0, f1;
       joint_frames(m, 0, &WORLD_X, &x[0], &f0);

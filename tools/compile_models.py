@@ -44,11 +44,11 @@ def main():
                       init_q_offset=spec.get("init_q_offset", ()),
                       gear_override=spec.get("gear_override", ()),
                       passive_joint_forces=spec.get("passive_joint_forces", True),
-                      reset_quat_raw=spec.get("reset_quat_raw", False))
+                      reset_quat_raw=spec.get("reset_quat_raw", False), planar=spec.get("planar"))
         with open(os.path.join(out, f"{name}.json"), "w") as f:
             f.write(m.to_json())
         print(f"{name}: L={m.n_links} nq={m.q_size()} nqd={m.qd_size()} nu={m.act_size()} "
-              f"ncol={m.fields['n_col']} iso={m.fields['iso_inertia']} mass={m.masses.sum():.3f}")
+              f"ncol={m.fields['n_col']} iso={m.fields['iso_inertia']} flags={m.fields['flags']} mass={m.masses.sum():.3f}")
     # demo trajectories
     xref = np.load(os.path.join(ref, "mbd", "assets", "car2d_xref.npy")).astype(np.float32)  # car2d.py:66
     np.save(os.path.join(out, "car2d_xref.npy"), xref)

@@ -24,6 +24,11 @@ INSTANCES = {
     "walker2d": "8,false,true,4,2,1,-3,0,0,true,false,2,true,true",
     "hopper": "4,false,true,4,2,1,0,0,0,true,false,2,true,true",
     "cartpole": "4,true,true,4,2,1,0,0,0,false,false,2,true",
+    # the planar restatement (mbd_planar.h: rollout_planar_kernel<LPS, MAXCOL, D0, D1>) the planar models actually run
+    "hopper_planar": "planar:4,2,1,0",
+    "halfcheetah_planar": "planar:8,2,1,-3",
+    "walker2d_planar": "planar:8,2,1,-3",
+    "cartpole_planar": "planar:4,0,1,0",
 }
 
 
@@ -31,14 +36,17 @@ def count(targs):
     csrc = os.path.join(ROOT, "model-based-diffusion_amd", "csrc")
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "k.hip")
+        kern, hdr = "rollout_kernel", "mbd_kernels.h"
+        if targs.startswith("planar:"):
+            kern, hdr, targs = "rollout_planar_kernel", "mbd_planar.h", targs[len("planar:"):]
         with open(src, "w") as f:
-            f.write(f'#include "{csrc}/mbd_kernels.h"\ntemplate __global__ void mbd::rollout_kernel<{targs}>(mbd::RolloutParams);\n')
+            f.write(f'#include "{csrc}/{hdr}"\ntemplate __global__ void mbd::{kern}<{targs}>(mbd::RolloutParams);\n')
         out = os.path.join(td, "k.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
                         "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-S", "--cuda-device-only", src,
                         "-o", out], check=True, capture_output=True)
         body = open(out).read().split("\n")
-    start = [i for i, l in enumerate(body) if re.match(r"^_ZN3mbd14rollout_kernel.*:", l)][0]
+    start = [i for i, l in enumerate(body) if re.match(r"^_ZN3mbd\d+rollout_(planar_)?kernel.*:", l)][0]
     end = [i for i, l in enumerate(body) if i > start and ".Lfunc_end" in l][0]
     meta = "\n".join(body[end:])
     body = body[start:end]
@@ -58,7 +66,7 @@ def count(targs):
     # longest region strictly inside it (the other backward branches in there are out-of-line slow paths — the exact
     # square root of the quaternion renormalisation — jumping back into the loop, and the small gather loops)
     outer = max(loops, key=lambda t: len(t[2]))
-    inner = [t for t in loops if t[0] > outer[0] and t[1] < outer[1] and len(t[2]) <= len(outer[2]) - 100]
+    inner = [t for t in loops if t[0] > outer[0] and t[1] < outer[1] and len(t[2]) <= len(outer[2]) - 40]
     best = max(inner, key=lambda t: len(t[2]))[2]
     c = collections.Counter(best)
     flops = 0
