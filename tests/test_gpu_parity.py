@@ -756,3 +756,29 @@ def test_noise_prefetch_is_bit_identical(gpu, impl, monkeypatch):
     assert np.array_equal(np.stack(mus), mu1) and np.array_equal(np.array(rms, np.float32), rm1)
     assert p2.eval(mu1[-1]) == rf1
     p2.close()
+
+
+@pytest.mark.parametrize("no_dpp", [False, True])
+@pytest.mark.parametrize("name,B", [("hopper", 200), ("walker2d", 72), ("halfcheetah", 136), ("cartpole", 100)])
+def test_general_3d_kernels_on_planar_models(gpu, orc_omp, name, B, no_dpp, monkeypatch):
+    """The planar models normally run the planar restatement (MBD_FLAG_PLANAR).  Compiled WITHOUT the flag (mjcf.load(
+    planar=False) — here: the flag cleared on the compiled model, passed through mbd_env_create_model) they take the
+    general 3-D slide-joint kernels (constant slide axes, packed collider pairs, axisymmetric inertia; DPP and shuffle
+    exchange), which must stay bit-exact against the 3-D restatement of the checker."""
+    if no_dpp:
+        monkeypatch.setenv("MBD_NO_DPP", "1")
+    from conftest import load_model
+    from mbd_hip.envs.base import RigidBodyEnv
+    from oracle.planner import OracleEnv
+    m = load_model(name)
+    m.fields["flags"] = int(m.fields["flags"]) & ~2
+    env = RigidBodyEnv(name, model=m)
+    assert not (int(env.sys.fields["flags"]) & 2)
+    st = env.reset(gpu.prng_key(3))
+    g = np.random.default_rng(B)
+    us = np.clip(g.normal(size=(B, 50, env.action_size)) * 0.8, -1.0, 1.0).astype(np.float32)
+    got = env.rollout(st, us).cpu().numpy()
+    oe = OracleEnv(orc_omp, name, m.to_struct(), init_q=m.init_q)
+    ref = oe.rollout(np.asarray(st.pipeline_state, np.float32), us)
+    assert np.isfinite(got).all()
+    assert np.array_equal(got, ref), f"{name}: max |d| = {np.abs(got - ref).max()}"

@@ -184,3 +184,46 @@ def test_cartpole_weld_limits_and_reward(orc):
         assert np.allclose(st[0, 3:7], [1, 0, 0, 0], atol=2e-3)   # the cart does not rotate
         assert abs(st[0, 1]) < 1e-3 and abs(st[0, 2]) < 8e-3      # and stays on its rail (soft PBD constraint)
     assert max(xs) < 1.0 + 0.15 and max(xs) > 0.9                # pressed against the soft +1 m limit
+
+
+# ---- the planar restatement (oracle/mbd_oracle_planar.h; MBD_FLAG_PLANAR) ---------------------------------------
+@pytest.mark.parametrize("name", ["hopper", "walker2d", "halfcheetah", "cartpole"])
+def test_planar_restatement_agrees_with_the_3d_one_per_control_step(orc, name):
+    """The planar models are simulated on their in-plane coordinates only (a specification of its own: the 3-D float
+    arithmetic is not exactly planar).  Teacher-forced from the SAME state, one control step (16-20 substeps) of the
+    planar restatement and of the general 3-D one must agree to float round-off — rewards to 2e-5, in-plane poses and
+    velocities to 1e-3 — while a free-running 3-D rollout leaks out of the plane and the planar one cannot."""
+    from oracle.planner import OracleEnv
+    m = load_model(name)
+    ms_pl, ms_3d = m.to_struct(), m.to_struct()
+    assert ms_pl.flags & 2, "the MJCF compiler marks this model planar"
+    ms_3d.flags = ms_3d.flags & ~2
+    env = OracleEnv(orc, name, ms_pl, init_q=m.init_q)
+    s = env.reset(orc.prng_key(3), 1)
+    inpl = [0, 2, 3, 5, 7, 9, 11]
+    outpl = [1, 4, 6, 8, 10, 12]
+    g = np.random.default_rng(1)
+    s3 = s.copy()
+    worst_state, worst_rew, leak = 0.0, 0.0, 0.0
+    for t in range(40):
+        a = np.clip(g.normal(size=m.act_size()) * 0.7, -1, 1).astype(np.float32)
+        n3, r3 = orc.env_step(ms_3d, s, a)
+        npl, rpl = orc.env_step(ms_pl, s, a)
+        worst_state = max(worst_state, float(np.abs(n3[:, inpl] - npl[:, inpl]).max()))
+        worst_rew = max(worst_rew, abs(float(r3) - float(rpl)))
+        assert np.all(npl[:, outpl] == 0.0), "the planar restatement never leaves the plane"
+        s3, _ = orc.env_step(ms_3d, s3, a)
+        leak = max(leak, float(np.abs(s3[:, outpl]).max()))
+        s = npl
+    assert worst_state < 1e-3 and worst_rew < 2e-5, (worst_state, worst_rew)
+    assert leak > 0.0, "the 3-D arithmetic does leak out of the plane (which is why planar is a spec of its own)"
+
+
+def test_planar_classification():
+    """mbd_hip.mjcf.is_planar: the four planar models qualify, the humanoids / ant (free root, 3-D joints) do not."""
+    from mbd_hip import mjcf
+    for name, want in (("hopper", True), ("walker2d", True), ("halfcheetah", True), ("cartpole", True),
+                       ("humanoidrun", False), ("ant", False), ("humanoidstandup", False), ("humanoidtrack", False)):
+        m = load_model(name)
+        assert mjcf.is_planar(m.fields) == want, name
+        assert bool(int(m.fields["flags"]) & 2) == want, name
