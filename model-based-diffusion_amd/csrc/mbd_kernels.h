@@ -41,6 +41,8 @@ struct RolloutParams {
   int slide_limits;  // any slide dof with a finite range (wave-uniform: the limit corrections are skipped otherwise)
   int max_children;  // largest child count in the model (wave-uniform bound of the generic kernels' child loops)
   int max_rot;       // largest number of hinge dofs on one joint (1: hopper, walker2d, halfcheetah, ant, cartpole)
+  int any_stiff;     // some hinge has a joint spring (rot_stiff != 0): wave-uniform, the planar kernels skip the
+                     // stage-(1) hinge angle otherwise (it only feeds the spring)
   int has_weld;      // some joint has no hinge dof (slide-only / weld: the cartpole's cart): wave-uniform, the orientation
                      // lock of stage (3) is skipped otherwise (it would be discarded by its select)
   // DPP instantiations only: lane (within the 16-lane row) <-> link tables, [0..15] lane -> link (-1: padding),

@@ -35,6 +35,19 @@ __device__ __forceinline__ float pl_angle(float wr, float yr) {
   const float cn = ffma(-(yr + yr), yr, 1.0f);
   return angle_unit(sn, cn);
 }
+// the same on (parent, child) or (collider 0, collider 1) pairs: one v_pk_* issue slot for both, identical roundings
+struct PCs2 { f2 c, s; };
+__device__ __forceinline__ PCs2 pl_cs2(f2 w, f2 y) {
+  const f2 y2 = y + y;
+  return PCs2{fma2(-y2, y, mk2(1.0f, 1.0f)), y2 * w};
+}
+__device__ __forceinline__ void pl_rot2(PCs2 a, f2 x, f2 z, f2& ox, f2& oz) {
+  ox = fma2(a.s, z, a.c * x);
+  oz = fma2(-a.s, x, a.c * z);
+}
+__device__ __forceinline__ f2 pl_cross2(f2 rx, f2 rz, f2 fx, f2 fz) { return fma2(rz, fx, -(rx * fz)); }
+__device__ __forceinline__ f2 bc2(float a) { return mk2(a, a); }
+
 template <bool NORMALIZE>
 __device__ __forceinline__ void pl_qupdate(float& w, float& y, float dth) {
   const float h = 0.5f * dth;
@@ -84,6 +97,9 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   const float apx = M->ap_pos[l][0], apz = M->ap_pos[l][2], acx = M->ac_pos[l][0], acz = M->ac_pos[l][2];
   const float sg = (M->ap_rot[l][0] * M->ap_rot[l][3] < 0.0f) ? -1.0f : 1.0f;
   const float wpar = world_parent ? 1.0f : 0.0f;  // the world's orientation (1, 0): added to the fetched zero
+  // (parent, child) pairs of the per-joint constants
+  const f2 anc_x = mk2(apx, acx), anc_z = mk2(apz, acz);
+  const f2 im2 = mk2(-im_p, im_c), iy2 = mk2(iy_p, iy_c), iy2s = mk2(-iy_p, iy_c);
   float sx[2], sz[2], sl_lo[2], sl_hi[2], sl_damp[2];
   {
     const q4 aprot = q4{M->ap_rot[l][0], M->ap_rot[l][1], M->ap_rot[l][2], M->ap_rot[l][3]};
@@ -226,19 +242,21 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       const float Pvx = from_parent(vx), Pvz = from_parent(vz), Pom = from_parent(om);
       float fcvx, fcvz, fcw, fpvx, fpvz, fpw;
       {
-        const PCs cP = pl_cs(Pw, Py), cC = pl_cs(qw, qy);
-        float rpx, rpz, rcx, rcz;
-        pl_rot(cP, apx, apz, rpx, rpz);
-        pl_rot(cC, acx, acz, rcx, rcz);
-        const float vpx = ffma(Pom, rpz, Pvx), vpz = ffma(-Pom, rpx, Pvz);
-        const float vcx = ffma(om, rcz, vx), vcz = ffma(-om, rcx, vz);
-        float rvx = vcx - vpx, rvz = vcz - vpz;
+        // (parent, child) pairs: low half the parent side, high half the child side
+        const PCs2 c2 = pl_cs2(mk2(Pw, qw), mk2(Py, qy));
+        f2 rx, rz;
+        pl_rot2(c2, anc_x, anc_z, rx, rz);  // the lever arms (rp, rc)
+        const f2 om2 = mk2(Pom, om);
+        const f2 vax = fma2(om2, rz, mk2(Pvx, vx)), vaz = fma2(-om2, rx, mk2(Pvz, vz));  // anchor velocities (vp, vc)
+        float rvx = vax.y - vax.x, rvz = vaz.y - vaz.x;
         const float rw = om - Pom;
-        float wr, yr;
-        pl_rel(Pw, Py, qw, qy, wr, yr);
-        const float ang = sg * pl_angle(wr, yr);
-        const float qd = sg * rw;
-        float fk = ffma(-stiff, ang, ffma(-damp, qd, tau0));
+        float fk = ffma(-damp, sg * rw, tau0);
+        if (P.any_stiff) {  // (wave-uniform) the hinge angle only feeds the joint spring: -0 * ang is an exact zero
+          float wr, yr;
+          pl_rel(Pw, Py, qw, qy, wr, yr);
+          const float ang = sg * pl_angle(wr, yr);
+          fk = ffma(-stiff, ang, fk);
+        }
         fk = nr >= 1 ? fk : 0.0f;
         const float Ty = ffma(-ang_damp, rw, fk * sg);
         float Fx = 0.0f, Fz = 0.0f;
@@ -250,10 +268,10 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
           rvx = ffma(-vs, sx[j], rvx); rvz = ffma(-vs, sz[j], rvz);
         }
         Fx = ffma(-vel_damp, rvx, Fx); Fz = ffma(-vel_damp, rvz, Fz);
-        fcvx = Fx * im_c; fcvz = Fz * im_c;
-        fcw = (Ty + pl_cross(rcx, rcz, Fx, Fz)) * iy_c;
-        fpvx = Fx * (-im_p); fpvz = Fz * (-im_p);
-        fpw = -((Ty + pl_cross(rpx, rpz, Fx, Fz)) * iy_p);
+        const f2 linx = bc2(Fx) * im2, linz = bc2(Fz) * im2;                   // (-F/m_p, F/m_c)
+        const f2 angw = (bc2(Ty) + pl_cross2(rx, rz, bc2(Fx), bc2(Fz))) * iy2;  // ((T + rp x F)/I_p, (T + rc x F)/I_c)
+        fpvx = linx.x; fcvx = linx.y; fpvz = linz.x; fcvz = linz.y;
+        fpw = -angw.x; fcw = angw.y;
       }
       // ---- (2) integrator.integrate_xdd ---------------------------------------------------------------------
       {
@@ -270,45 +288,44 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       Ppx = from_parent(px); Ppz = from_parent(pz); Pw = from_parent(qw) + wpar; Py = from_parent(qy);
       float dcx, dcz, dcth, dpx, dpz, dpth;
       {
-        const PCs cP = pl_cs(Pw, Py), cC = pl_cs(qw, qy);
-        float rpx, rpz, rcx, rcz;
-        pl_rot(cP, apx, apz, rpx, rpz);
-        pl_rot(cC, acx, acz, rcx, rcz);
-        const float apwx = Ppx + rpx, apwz = Ppz + rpz, acwx = px + rcx, acwz = pz + rcz;
-        float dx = apwx - acwx, dz = apwz - acwz;
+        const PCs2 c2p = pl_cs2(mk2(Pw, qw), mk2(Py, qy));
+        f2 rx, rz;
+        pl_rot2(c2p, anc_x, anc_z, rx, rz);
+        const f2 awx = mk2(Ppx, px) + rx, awz = mk2(Ppz, pz) + rz;  // world anchors (ap, ac)
+        float dx = awx.x - awx.y, dz = awz.x - awz.y;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const float cf = -ffma(dx, sx[j], dz * sz[j]);
           dx = ffma(cf, sx[j], dx); dz = ffma(cf, sz[j], dz);
         }
         const float c2 = ffma(dx, dx, dz * dz);
-        const float crp = pl_cross(rpx, rpz, dx, dz), crc = pl_cross(rcx, rcz, dx, dz);
-        const float wq = crp * (iy_p * crp) + crc * (iy_c * crc);
-        const float den = ffma(invm_sum, c2, wq) + 1e-20f;
+        const f2 cr = pl_cross2(rx, rz, bc2(dx), bc2(dz));
+        const f2 wq2 = cr * (iy2 * cr);
+        const float den = ffma(invm_sum, c2, wq2.x + wq2.y) + 1e-20f;
         const float g = div_pos_(c2, den) * js_pos;
         const float Px = dx * g, Pz = dz * g;
-        dcx = Px * im_c; dcz = Pz * im_c;
-        dpx = Px * (-im_p); dpz = Pz * (-im_p);
-        dcth = pl_cross(rcx, rcz, Px, Pz) * iy_c;
-        dpth = -(pl_cross(rpx, rpz, Px, Pz) * iy_p);
+        f2 lx2 = bc2(Px) * im2, lz2 = bc2(Pz) * im2;                      // (dp_p, dc_p)
+        const f2 t2 = pl_cross2(rx, rz, bc2(Px), bc2(Pz)) * iy2;
+        f2 th2 = mk2(-t2.x, t2.y);                                         // (dp_th, dc_th)
         if (P.slide_limits) {  // (wave-uniform)
-          const float ex = acwx - apwx, ez = acwz - apwz;
+          const float ex = awx.y - awx.x, ez = awz.y - awz.x;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
             const float qs = ffma(ex, sx[j], ez * sz[j]);
             const float viol = qs - fclip(qs, sl_lo[j], sl_hi[j]);
             const float lx = sx[j] * (-viol), lz = sz[j] * (-viol);
             const float l2 = ffma(lx, lx, lz * lz);
-            const float lp = pl_cross(rpx, rpz, lx, lz), lc = pl_cross(rcx, rcz, lx, lz);
-            const float dens = ffma(invm_sum, l2, lp * (iy_p * lp) + lc * (iy_c * lc));
+            const f2 lcr = pl_cross2(rx, rz, bc2(lx), bc2(lz));
+            const f2 lw = lcr * (iy2 * lcr);
+            const float dens = ffma(invm_sum, l2, lw.x + lw.y);
             const float gs = div_pos_(l2, dens + 1e-20f) * js_pos;
             const float Sx = lx * gs, Sz = lz * gs;
-            dcx = ffma(Sx, im_c, dcx); dcz = ffma(Sz, im_c, dcz);
-            dpx = ffma(Sx, -im_p, dpx); dpz = ffma(Sz, -im_p, dpz);
-            dcth = ffma(pl_cross(rcx, rcz, Sx, Sz), iy_c, dcth);
-            dpth = ffma(pl_cross(rpx, rpz, Sx, Sz), -iy_p, dpth);
+            lx2 = fma2(bc2(Sx), im2, lx2); lz2 = fma2(bc2(Sz), im2, lz2);
+            th2 = fma2(pl_cross2(rx, rz, bc2(Sx), bc2(Sz)), iy2s, th2);
           }
         }
+        dpx = lx2.x; dcx = lx2.y; dpz = lz2.x; dcz = lz2.y;
+        dpth = th2.x; dcth = th2.y;
         float wr, yr;
         pl_rel(Pw, Py, qw, qy, wr, yr);
         const float ang = sg * pl_angle(wr, yr);
@@ -329,7 +346,44 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       bool cact[MAXCOL > 0 ? MAXCOL : 1];
       {
         float cdx = 0.0f, cdz = 0.0f, cdth = 0.0f;
-        if constexpr (MAXCOL > 0) {
+        if constexpr (MAXCOL == 2) {
+          // both colliders of the link as one packed pair (the solve is Jacobi: each sees the pose of the stage's
+          // start); their corrections are then added in collider order
+          const PCs a = pl_cs(qw, qy), ap = pl_cs(qwp, qyp);
+          const f2 cx2 = mk2(colx[0], colx[1]), cz2 = mk2(colz[0], colz[1]), rad2 = mk2(col_rad[0], col_rad[1]);
+          const f2 offx = fma2(bc2(a.s), cz2, bc2(a.c) * cx2), offz = fma2(bc2(-a.s), cx2, bc2(a.c) * cz2);
+          const f2 ctrx = bc2(px) + offx, ctrz = bc2(pz) + offz;
+          const f2 pen = rad2 - ctrz;
+          const bool act0 = col_has[0] && pen.x > 0.0f, act1 = col_has[1] && pen.y > 0.0f;
+          const f2 h = fma2(bc2(-0.5f), pen, rad2);
+          const f2 posx = ctrx, posz = ctrz - h;
+          const f2 rcx = offx, rcz = offz - h;
+          const f2 icn = rcx * bc2(iy_c);
+          const f2 wn = fma2(icn, rcx, bc2(im_c));
+          const f2 d = -h;
+          const f2 rlx = fma2(bc2(-a.s), d, cx2), rlz = fma2(bc2(a.c), d, cz2);
+          const f2 pprevx = bc2(pxp) + fma2(bc2(ap.s), rlz, bc2(ap.c) * rlx);
+          const f2 ddx = posx - pprevx;
+          const f2 ct2 = ddx * ddx;
+          const f2 cnt = rcz * ddx;
+          const f2 dent = fma2(bc2(im_c), ct2, cnt * (cnt * bc2(iy_c)));
+          f2 q_n, q_g;
+          div2x2_(pen, wn, ct2, dent + bc2(1e-20f), q_n, q_g);
+          const f2 dlam = q_n * bc2(coll_scale), gt = q_g;
+          const f2 lim = bc2(mu) * dlam;
+          const f2 lhs = (ct2 * gt) * gt, rhs = lim * lim;
+          const f2 praw = (-gt) * ddx;
+          const f2 Pix = mk2(lhs.x < rhs.x ? praw.x : 0.0f, lhs.y < rhs.y ? praw.y : 0.0f), Piz = dlam;
+          const f2 dth = pl_cross2(rcx, rcz, Pix, Piz) * bc2(iy_c);
+          cdx = act0 ? ffma(im_c, Pix.x, cdx) : cdx;
+          cdz = act0 ? ffma(im_c, Piz.x, cdz) : cdz;
+          cdth = act0 ? cdth + dth.x : cdth;
+          cdx = act1 ? ffma(im_c, Pix.y, cdx) : cdx;
+          cdz = act1 ? ffma(im_c, Piz.y, cdz) : cdz;
+          cdth = act1 ? cdth + dth.y : cdth;
+          cposx[0] = posx.x; cposx[1] = posx.y; cposz[0] = posz.x; cposz[1] = posz.y;
+          cdlam[0] = dlam.x; cdlam[1] = dlam.y; cact[0] = act0; cact[1] = act1;
+        } else         if constexpr (MAXCOL > 0) {
           const PCs a = pl_cs(qw, qy), ap = pl_cs(qwp, qyp);
 #pragma unroll
           for (int j = 0; j < MAXCOL; ++j) {
