@@ -49,10 +49,10 @@ CONFIGS = {
     # name: env, N, H, Ndiffuse, temp, demo, lanes per candidate (rollout kernel), kernel label
     "metric": dict(env="humanoidrun", N=1024, H=50, Nd=100, temp=0.1, demo=False, lps=16,
                    kernel="rollout_kernel<16,iso,noslide,3,1,dpp(1,-4,-6)>"),
-    "hopper512": dict(env="hopper", N=512, H=50, Nd=100, temp=0.1, demo=False, lps=4,
-                      kernel="rollout_kernel<4,aniso-diag,slides,dpp(1)>"),
+    "hopper512": dict(env="hopper", N=512, H=50, Nd=100, temp=0.1, demo=False, lps=4, static="hopper_planar",
+                      kernel="rollout_planar_kernel<4,2 colliders,dpp(1)>"),
     "halfcheetah1024": dict(env="halfcheetah", N=1024, H=50, Nd=100, temp=0.4, demo=False, lps=8,
-                            kernel="rollout_kernel<8,iso,slides,dpp(1,-3)>"),
+                            static="halfcheetah_planar", kernel="rollout_planar_kernel<8,2 colliders,dpp(1,-3)>"),
     "humanoidrun4096": dict(env="humanoidrun", N=4096, H=50, Nd=100, temp=0.1, demo=False, lps=16,
                             kernel="rollout_kernel<16,iso,noslide,3,1,dpp(1,-4,-6)>"),
     "humanoidtrack2048demo": dict(env="humanoidtrack", N=2048, H=50, Nd=100, temp=0.1, demo=True, lps=16,
@@ -116,7 +116,7 @@ def valu_view(cfg, n_local, kern_ms, n_frames, fsub, fsub_src):
         out.update(achieved=tf, frac=tf / VALU_PEAK_TF, algorithmic_frac=tf / VALU_PEAK_TF, flops_per_launch=flops,
                    flops_per_substep=fsub["flops"], op_counts=fsub, source=fsub_src)
     st, src = committed("static_flops.json")
-    ent = (st or {}).get(cfg["env"]) or (st if st and cfg["env"] == "humanoidrun" and "valu_per_substep" in st else None)
+    ent = (st or {}).get(cfg.get("static", cfg["env"]))
     if ent:
         fl = ent["fp32_flops_per_lane_substep"] * 64.0 * waves * substeps
         out["issued"] = {"flops_per_launch": fl, "achieved": fl / (kern_ms * 1e-3) / 1e12,
