@@ -106,6 +106,48 @@ MBD_DPP_ACC6(6, "row_shl:6")
 MBD_DPP_ACC6(3, "row_shl:3")
 MBD_DPP_ACC6(2, "row_shl:2")
 #undef MBD_DPP_ACC6
+// The three child slots of the humanoid layout (shifts -1, +4, +6) in ONE block: one hazard s_nop for 18 accumulations
+// (an "s_nop 1" costs a lone wavefront two whole issue slots, tools/probes/probe_issue.hip).
+#define MBD_F6(MOD, M)                                                                                        \
+  "v_fmac_f32_dpp %0, %6, %" #M " " MOD " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                        \
+  "v_fmac_f32_dpp %1, %7, %" #M " " MOD " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                        \
+  "v_fmac_f32_dpp %2, %8, %" #M " " MOD " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                        \
+  "v_fmac_f32_dpp %3, %9, %" #M " " MOD " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                        \
+  "v_fmac_f32_dpp %4, %10, %" #M " " MOD " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"                       \
+  "v_fmac_f32_dpp %5, %11, %" #M " " MOD " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+__device__ __forceinline__ void dpp_acc6x3(v3& a, v3& b, v3 x, v3 y, float m0, float m1, float m2) {
+  asm("s_nop 1\n\t" MBD_F6("row_shr:1", 12) MBD_F6("row_shl:4", 13) MBD_F6("row_shl:6", 14)
+      : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z)
+      : "v"(x.x), "v"(x.y), "v"(x.z), "v"(y.x), "v"(y.y), "v"(y.z), "v"(m0), "v"(m1), "v"(m2));
+}
+// The same with two independent products t0 = f * u0, t1 = f * u1 riding in place of the s_nop: they are the two
+// wait states between any earlier write of x / y and the first DPP read (t0, t1 are early-clobber outputs, so they
+// never alias a DPP source), and they are work the caller needs anyway (v_mul_f32 rounds like the compiler's product).
+__device__ __forceinline__ void dpp_acc6x3_mul2(v3& a, v3& b, v3 x, v3 y, float m0, float m1, float m2, float f,
+                                                float u0, float u1, float& t0, float& t1) {
+  asm("v_mul_f32_e32 %6, %17, %18\n\tv_mul_f32_e32 %7, %17, %19\n\t"
+      "v_fmac_f32_dpp %0, %8, %14 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %1, %9, %14 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %2, %10, %14 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %3, %11, %14 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %4, %12, %14 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %5, %13, %14 row_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, %8, %15 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %1, %9, %15 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %2, %10, %15 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %3, %11, %15 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %4, %12, %15 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %5, %13, %15 row_shl:4 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %0, %8, %16 row_shl:6 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %1, %9, %16 row_shl:6 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %2, %10, %16 row_shl:6 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %3, %11, %16 row_shl:6 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %4, %12, %16 row_shl:6 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+      "v_fmac_f32_dpp %5, %13, %16 row_shl:6 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+      : "+v"(a.x), "+v"(a.y), "+v"(a.z), "+v"(b.x), "+v"(b.y), "+v"(b.z), "=&v"(t0), "=&v"(t1)
+      : "v"(x.x), "v"(x.y), "v"(x.z), "v"(y.x), "v"(y.y), "v"(y.z), "v"(m0), "v"(m1), "v"(m2), "v"(f), "v"(u0), "v"(u1));
+}
+#undef MBD_F6
 // the parent's pose for the s-th child (mask m_s = 1): seven values, r = x(i+K0) m0 + x(i+K1) m1 + x(i+K2) m2
 template <int K0, int K1, int K2>
 __device__ __forceinline__ void dpp_fetch7(v3 p, q4 r, float m0, float m1, float m2, v3& Pp, q4& Pr);
@@ -737,14 +779,21 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
       }
       // ---- (2) integrator.integrate_xdd -------------------------------------------------------------
       v3x2 acc = pack3(fc_v, fc_w);  // (linear, angular) acceleration, packed
+      float damped_vx = 0.0f, damped_vy = 0.0f;  // vel_fac * v.{x,y}: computed inside the humanoids' exchange block
+      bool have_damped = false;
       {
         v3 cv[MAXCH], cw[MAXCH];
         if constexpr (DPP) {  // ((own + child 0) + child 1) + child 2, as in the shuffle path
           v3 sv = fc_v, sw = fc_w;
-          dpp_acc6<-D0>(sv, sw, fp_v, fp_w, rm[0]);
-          if constexpr (D1 != 0) dpp_acc6<-D1>(sv, sw, fp_v, fp_w, rm[1]);
-          if constexpr (D2 != 0) dpp_acc6<-D2>(sv, sw, fp_v, fp_w, rm[2]);
-          if constexpr (D3 != 0) dpp_acc6<-D3>(sv, sw, fp_v, fp_w, rm[3]);
+          if constexpr (D0 == 1 && D1 == -4 && D2 == -6 && D3 == 0) {  // (the humanoids: one block, no s_nop)
+            dpp_acc6x3_mul2(sv, sw, fp_v, fp_w, rm[0], rm[1], rm[2], vel_fac, v.x, v.y, damped_vx, damped_vy);
+            have_damped = true;
+          } else {
+            dpp_acc6<-D0>(sv, sw, fp_v, fp_w, rm[0]);
+            if constexpr (D1 != 0) dpp_acc6<-D1>(sv, sw, fp_v, fp_w, rm[1]);
+            if constexpr (D2 != 0) dpp_acc6<-D2>(sv, sw, fp_v, fp_w, rm[2]);
+            if constexpr (D3 != 0) dpp_acc6<-D3>(sv, sw, fp_v, fp_w, rm[3]);
+          }
           acc = pack3(sv, sw);
         } else {
 #pragma unroll
@@ -764,7 +813,8 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         }
       }
       const v3 av = lo3(acc), aw = hi3(acc);
-      v = mk3(ffma(av.x + grav.x, dt, vel_fac * v.x), ffma(av.y + grav.y, dt, vel_fac * v.y),
+      if (!have_damped) { damped_vx = vel_fac * v.x; damped_vy = vel_fac * v.y; }
+      v = mk3(ffma(av.x + grav.x, dt, damped_vx), ffma(av.y + grav.y, dt, damped_vy),
               ffma(av.z + grav.z, dt, vel_fac * v.z));
       w = mk3(ffma(aw.x, dt, ang_fac * w.x), ffma(aw.y, dt, ang_fac * w.y), ffma(aw.z, dt, ang_fac * w.z));
       const v3 p_prev = p;
@@ -809,7 +859,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         v3 e = scale(cross(A, Bv), sc);
         if (SLIDES && P.has_weld) {  // joints without a hinge dof keep the child's orientation locked to the parent's
           q4 qe = qmul(f.aprot, conj(f.acrot));
-          float sg = qe.w < 0.0f ? -2.0f : 2.0f;
+          float sg = __builtin_copysignf(2.0f, qe.w);
           e = sel3(nr_eff == 0, mk3(sg * qe.x, sg * qe.y, sg * qe.z), e);
         }
         // a - clamp(a, lo, hi): a-lo below, a-hi above, 0 inside; a select discards the slots the joint lacks
@@ -914,10 +964,14 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         v3x2 acc = pack3(dc_p, dc_th);  // (translation, rotation vector), packed
         if constexpr (DPP) {
           v3 sp = dc_p, sth = dc_th;
-          dpp_acc6<-D0>(sp, sth, dp_p, dp_th, rm[0]);
-          if constexpr (D1 != 0) dpp_acc6<-D1>(sp, sth, dp_p, dp_th, rm[1]);
-          if constexpr (D2 != 0) dpp_acc6<-D2>(sp, sth, dp_p, dp_th, rm[2]);
-          if constexpr (D3 != 0) dpp_acc6<-D3>(sp, sth, dp_p, dp_th, rm[3]);
+          if constexpr (D0 == 1 && D1 == -4 && D2 == -6 && D3 == 0) {
+            dpp_acc6x3(sp, sth, dp_p, dp_th, rm[0], rm[1], rm[2]);
+          } else {
+            dpp_acc6<-D0>(sp, sth, dp_p, dp_th, rm[0]);
+            if constexpr (D1 != 0) dpp_acc6<-D1>(sp, sth, dp_p, dp_th, rm[1]);
+            if constexpr (D2 != 0) dpp_acc6<-D2>(sp, sth, dp_p, dp_th, rm[2]);
+            if constexpr (D3 != 0) dpp_acc6<-D3>(sp, sth, dp_p, dp_th, rm[3]);
+          }
           acc = pack3(sp, sth);
         } else {
 #pragma unroll
@@ -1038,7 +1092,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
       v = mk3((p.x - p_prev.x) * inv_dt, (p.y - p_prev.y) * inv_dt, (p.z - p_prev.z) * inv_dt);
       {
         q4 dq = qmul(r, conj(r_prev));
-        float s = dq.w < 0.0f ? -two_inv_dt : two_inv_dt;
+        float s = __builtin_copysignf(two_inv_dt, dq.w);
         w = mk3(dq.x * s, dq.y * s, dq.z * s);
       }
       // ---- (6) collisions.resolve_velocity --------------------------------------------------------------

@@ -284,7 +284,10 @@ __device__ __forceinline__ void div2x2_(f2 na, f2 da, f2 nb, f2 db, f2& qa_out, 
   qa_out = fma2(ea, ra, qa); qb_out = fma2(eb, rb, qb);
 }
 
-// angle of the near-unit vector (c, s) in (-pi, pi], division-free: asin of min(|s|,|c|) + octant fix-ups
+// angle of the near-unit vector (c, s) in (-pi, pi], division-free: asin of min(|s|,|c|) + octant fix-ups.  The
+// result takes the SIGN BIT of s (one v_bfi instead of a compare and a select; a VALU compare holds a lone
+// wavefront's issue port for two slots).  The reflection about pi/2 stays a compare: the same trick there
+// (fma(copysign(1, c), r, pi/2 - copysign(pi/2, c))) measured 0.9 % SLOWER on the humanoid kernel.
 MBD_HD float angle_unit(float s, float c) {
   float as = fabs_(s), ac = fabs_(c);
   bool swap = as > ac;
@@ -300,7 +303,7 @@ MBD_HD float angle_unit(float s, float c) {
   float r = ffma(p * z, u, u);
   r = swap ? 1.57079632679489661923f - r : r;
   r = c < 0.0f ? 3.14159265358979323846f - r : r;
-  return s < 0.0f ? -r : r;
+  return __builtin_copysignf(r, s);
 }
 // the same for c >= 0 (the middle Euler angle: c = cos b is a square root): no reflection about pi/2
 MBD_HD float angle_unit_cpos(float s, float c) {
@@ -317,7 +320,7 @@ MBD_HD float angle_unit_cpos(float s, float c) {
   p = ffma(p, z, 0.16666975617408752f);
   float r = ffma(p * z, u, u);
   r = swap ? 1.57079632679489661923f - r : r;
-  return s < 0.0f ? -r : r;
+  return __builtin_copysignf(r, s);
 }
 // two angle_unit() evaluations at once (the polynomial runs on packed pairs)
 __device__ __forceinline__ f2 angle_unit2(f2 s, f2 c) {
@@ -338,7 +341,7 @@ __device__ __forceinline__ f2 angle_unit2(f2 s, f2 c) {
   r1 = sw1 ? 1.57079632679489661923f - r1 : r1;
   r0 = c.x < 0.0f ? 3.14159265358979323846f - r0 : r0;
   r1 = c.y < 0.0f ? 3.14159265358979323846f - r1 : r1;
-  return mk2(s.x < 0.0f ? -r0 : r0, s.y < 0.0f ? -r1 : r1);
+  return mk2(__builtin_copysignf(r0, s.x), __builtin_copysignf(r1, s.y));
 }
 MBD_HD void sincos_(float x, float* s_out, float* c_out) {
   float k = __builtin_rintf(x * 0.63661977236758134308f);

@@ -331,7 +331,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         const float ang = sg * pl_angle(wr, yr);
         const float viol = ang - fclip(ang, lim_lo, lim_hi);
         const float E_hinge = (-viol) * sg;
-        const float E_weld = (wr < 0.0f ? -2.0f : 2.0f) * (-yr);
+        const float E_weld = __builtin_copysignf(2.0f, wr) * (-yr);
         const float E = nr < 1 ? E_weld : E_hinge;
         dcth = ffma(kc, E, dcth);
         dpth = ffma(-kp, E, dpth);
@@ -364,16 +364,14 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
           const f2 rlx = fma2(bc2(-a.s), d, cx2), rlz = fma2(bc2(a.c), d, cz2);
           const f2 pprevx = bc2(pxp) + fma2(bc2(ap.s), rlz, bc2(ap.c) * rlx);
           const f2 ddx = posx - pprevx;
-          const f2 ct2 = ddx * ddx;
-          const f2 cnt = rcz * ddx;
-          const f2 dent = fma2(bc2(im_c), ct2, cnt * (cnt * bc2(iy_c)));
+          // static friction: the tangent is the x axis, |d|^2 / (d.W d) of the 3-D form is 1 / (im + rcz^2 iy)
+          const f2 wt = fma2(rcz, rcz * bc2(iy_c), bc2(im_c));
           f2 q_n, q_g;
-          div2x2_(pen, wn, ct2, dent + bc2(1e-20f), q_n, q_g);
-          const f2 dlam = q_n * bc2(coll_scale), gt = q_g;
+          div2x2_(pen, wn, bc2(1.0f), wt, q_n, q_g);
+          const f2 dlam = q_n * bc2(coll_scale), sx = q_g * ddx;
           const f2 lim = bc2(mu) * dlam;
-          const f2 lhs = (ct2 * gt) * gt, rhs = lim * lim;
-          const f2 praw = (-gt) * ddx;
-          const f2 Pix = mk2(lhs.x < rhs.x ? praw.x : 0.0f, lhs.y < rhs.y ? praw.y : 0.0f), Piz = dlam;
+          const f2 lhs = sx * sx, rhs = lim * lim;
+          const f2 Pix = mk2(lhs.x < rhs.x ? -sx.x : 0.0f, lhs.y < rhs.y ? -sx.y : 0.0f), Piz = dlam;
           const f2 dth = pl_cross2(rcx, rcz, Pix, Piz) * bc2(iy_c);
           cdx = act0 ? ffma(im_c, Pix.x, cdx) : cdx;
           cdz = act0 ? ffma(im_c, Piz.x, cdz) : cdz;
@@ -401,13 +399,11 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
             const float rlx = ffma(-a.s, d, colx[j]), rlz = ffma(a.c, d, colz[j]);
             const float pprevx = pxp + ffma(ap.s, rlz, ap.c * rlx);
             const float ddx = posx - pprevx;
-            const float ct2 = ddx * ddx;
-            const float cnt = rcz * ddx;
-            const float dent = ffma(im_c, ct2, cnt * (cnt * iy_c));
-            const f2 q_ng = div2_pos_(mk2(pen, ct2), mk2(wn, dent + 1e-20f));
-            const float dlam = q_ng.x * coll_scale, gt = q_ng.y;
+            const float wt = ffma(rcz, rcz * iy_c, im_c);
+            const f2 q_ng = div2_pos_(mk2(pen, 1.0f), mk2(wn, wt));
+            const float dlam = q_ng.x * coll_scale, sx = q_ng.y * ddx;
             const float lim = mu * dlam;
-            const float Pix = ((ct2 * gt) * gt < lim * lim) ? (-gt) * ddx : 0.0f, Piz = dlam;
+            const float Pix = (sx * sx < lim * lim) ? -sx : 0.0f, Piz = dlam;
             const float dth = pl_cross(rcx, rcz, Pix, Piz) * iy_c;
             cdx = active ? ffma(im_c, Pix, cdx) : cdx;
             cdz = active ? ffma(im_c, Piz, cdz) : cdz;
@@ -425,7 +421,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       {
         const float dqw = ffma(qw, qwp, qy * qyp);
         const float dqy = ffma(qy, qwp, -(qw * qyp));
-        om = dqy * (dqw < 0.0f ? -two_inv_dt : two_inv_dt);
+        om = dqy * __builtin_copysignf(two_inv_dt, dqw);
       }
       // ---- (6) collisions.resolve_velocity (sequential per link) ---------------------------------------------
       if constexpr (MAXCOL > 0) {
@@ -435,20 +431,17 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
           const float vptx = ffma(om, rcz, vx), vptz = ffma(-om, rcx, vz);
           float vn_prev = 0.0f;
           if (elast != 0.0f) vn_prev = ffma(-om_old, rcx, vz_old);  // (wave-uniform; with e = 0 the term is exactly 0)
+          // (in the plane the slip direction is the sign of vptx: no normalising division, lever arm rcz)
           const float vtn = fabs_(vptx);
-          const float inv = div_(1.0f, vtn + 1e-10f);
-          const float dir = vptx * inv;
           const float icn = rcx * iy_c;
           const float wn = ffma(icn, rcx, im_c);
-          const float cdv = rcz * dir;
-          const float wt = ffma(cdv, cdv * iy_c, im_c);
+          const float wt = ffma(rcz, rcz * iy_c, im_c);
           const float rest = -elast * vn_prev;
           const float dvn = fmin_(rest, 0.0f) - vptz;
           const float jt_max = (mu * cdlam[j]) * inv_dt;
           const float dvt = fmin_(jt_max * wt, vtn);
           const f2 q_nt = div2_sp_(mk2(dvn, dvt), mk2(wn, wt));
-          const float jn = q_nt.x, jt = -q_nt.y;
-          const float Pix = dir * jt, Piz = jn;
+          const float Pix = -__builtin_copysignf(q_nt.y, vptx), Piz = q_nt.x;  // friction opposes the slip
           const float nvx = ffma(im_c, Pix, vx), nvz = ffma(im_c, Piz, vz);
           const float nom = om + pl_cross(rcx, rcz, Pix, Piz) * iy_c;
           vx = cact[j] ? nvx : vx; vz = cact[j] ? nvz : vz; om = cact[j] ? nom : om;

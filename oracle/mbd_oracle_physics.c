@@ -397,7 +397,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     if (nr == 0) {
       real qc[4] = {f.acrot[0], -f.acrot[1], -f.acrot[2], -f.acrot[3]}, qe[4];
       sp_qmul(f.aprot, qc, qe);
-      real s = qe[0] < R(0) ? R(-2) : R(2);
+      real s = sp_copysign(R(2), qe[0]);
       sp_set3(e, s * qe[1], s * qe[2], s * qe[3]);
     } else {
       const real* A = nr == 1 ? f.Xc : f.Xp;
@@ -502,7 +502,7 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     for (int i = 0; i < 3; ++i) xd[l].v[i] = (x[l].p[i] - x_prev[l].p[i]) * inv_dt;
     real qc[4] = {x_prev[l].r[0], -x_prev[l].r[1], -x_prev[l].r[2], -x_prev[l].r[3]}, dq[4];
     sp_qmul(x[l].r, qc, dq);
-    real s = (dq[0] < R(0) ? R(-2) : R(2)) * inv_dt;
+    real s = sp_copysign(R(2), dq[0]) * inv_dt;
     for (int i = 0; i < 3; ++i) xd[l].w[i] = dq[1 + i] * s;
   }
   dump_stage(4, L, x, xd); /* (5) */

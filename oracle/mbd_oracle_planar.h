@@ -231,7 +231,7 @@ static void substep_planar(const mbd_model_t* m, pxf_t* x, pmo_t* xd, const real
     pl_rel(P->qw, P->qy, x[l].qw, x[l].qy, &wr, &yr);
     real E;
     if (m->n_rot[l] < 1) {
-      E = (wr < R(0) ? R(-2) : R(2)) * (-yr);
+      E = sp_copysign(R(2), wr) * (-yr);
     } else {
       const real ang = K[l].sg * pl_angle(wr, yr);
       const real viol = ang - sp_clip(ang, R(m->rot_lo[l][0]), R(m->rot_hi[l][0]));
@@ -273,14 +273,13 @@ static void substep_planar(const mbd_model_t* m, pxf_t* x, pmo_t* xd, const real
     const real rlx = sp_fma(-a.s, d, cx), rlz = sp_fma(a.c, d, cz); /* collider offset + the drop rotated back */
     const real pprevx = x_prev[l].px + sp_fma(ap.s, rlz, ap.c * rlx);
     const real ddx = cposx[k] - pprevx;
-    const real ct2 = ddx * ddx;
-    const real cnt = rcz * ddx;
-    const real dent = sp_fma(K[l].im, ct2, cnt * (cnt * K[l].iy));
+    /* static friction: the tangent is the x axis, so |d|^2 / (d.W d) of the 3-D form is 1 / (im + rcz^2 iy) */
+    const real wt = sp_fma(rcz, rcz * K[l].iy, K[l].im);
     const real dlam = sp_div_pos(pen, wn) * R(m->collide_scale);
-    const real gt = sp_div_pos(ct2, dent + R(1e-20));
+    const real sx = sp_div_pos(R(1), wt) * ddx;
     cdlam[k] = dlam;
     const real lim = mu * dlam;
-    const real Pix = ((ct2 * gt) * gt < lim * lim) ? (-gt) * ddx : R(0), Piz = dlam;
+    const real Pix = (sx * sx < lim * lim) ? -sx : R(0), Piz = dlam;
     const real dth = pl_cross(rcx, rcz, Pix, Piz) * K[l].iy;
     if (act[k]) { /* (onto exact zeros for the first active collider of a link) */
       cdx[l] = sp_fma(K[l].im, Pix, cdx[l]); cdz[l] = sp_fma(K[l].im, Piz, cdz[l]); cdth[l] = cdth[l] + dth;
@@ -299,7 +298,7 @@ static void substep_planar(const mbd_model_t* m, pxf_t* x, pmo_t* xd, const real
     xd[l].vz = (x[l].pz - x_prev[l].pz) * inv_dt;
     const real dqw = sp_fma(x[l].qw, x_prev[l].qw, x[l].qy * x_prev[l].qy);
     const real dqy = sp_fma(x[l].qy, x_prev[l].qw, -(x[l].qw * x_prev[l].qy));
-    xd[l].om = dqy * (dqw < R(0) ? -two_inv_dt : two_inv_dt);
+    xd[l].om = dqy * sp_copysign(two_inv_dt, dqw);
   }
   PL_DUMP(4);
   /* ---- (6) collisions.resolve_velocity (sequential per link) ------------------------------------------ */
@@ -309,19 +308,18 @@ static void substep_planar(const mbd_model_t* m, pxf_t* x, pmo_t* xd, const real
     const real rcx = cposx[k] - x[l].px, rcz = cposz[k] - x[l].pz;
     const real vptx = sp_fma(xd[l].om, rcz, xd[l].vx), vptz = sp_fma(-xd[l].om, rcx, xd[l].vz);
     const real vn_prev = sp_fma(-xd_old[l].om, rcx, xd_old[l].vz);
+    /* in the plane the slip direction is a SIGN (the 3-D form's vt / (|vt| + 1e-10) is +-1 up to 1e-10 / |vt|):
+     * no division, the tangential lever arm is rcz itself */
     const real vtn = sp_abs(vptx);
-    const real inv = sp_div(R(1), vtn + R(1e-10));
-    const real dir = vptx * inv;
     const real icn = rcx * K[l].iy;
     const real wn = sp_fma(icn, rcx, K[l].im);
-    const real cdv = rcz * dir;
-    const real wt = sp_fma(cdv, cdv * K[l].iy, K[l].im);
+    const real wt = sp_fma(rcz, rcz * K[l].iy, K[l].im);
     const real rest = -R(m->elasticity) * vn_prev;
     const real dvn = sp_min(rest, R(0)) - vptz;
     const real jt_max = (mu * cdlam[k]) * inv_dt;
     const real dvt = sp_min(jt_max * wt, vtn);
-    const real jn = sp_div(dvn, wn), jt = -sp_div_pos(dvt, wt);
-    const real Pix = dir * jt, Piz = jn;
+    const real jn = sp_div(dvn, wn);
+    const real Pix = -sp_copysign(sp_div_pos(dvt, wt), vptx), Piz = jn; /* friction opposes the slip */
     xd[l].vx = sp_fma(K[l].im, Pix, xd[l].vx);
     xd[l].vz = sp_fma(K[l].im, Piz, xd[l].vz);
     xd[l].om = xd[l].om + pl_cross(rcx, rcz, Pix, Piz) * K[l].iy;

@@ -23,7 +23,7 @@ LINK_STATE = 13
 def build(force: bool = False) -> None:
     """Compile the oracle with gcc (seconds). Building the checker is not using it."""
     libs = ["liboracle_f32.so", "liboracle_f64.so", "liboracle_f32_omp.so", "liboracle_count.so"]
-    srcs = [os.path.join(_HERE, s) for s in ("mbd_oracle_core.c", "mbd_oracle_physics.c", "spec_math.h", "count_ops.cc")]
+    srcs = [os.path.join(_HERE, s) for s in ("mbd_oracle_core.c", "mbd_oracle_physics.c", "mbd_oracle_planar.h", "spec_math.h", "count_ops.cc")]
     srcs.append(os.path.join(_HERE, "..", "include", "mbd_hip.h"))
     newest = max(os.path.getmtime(s) for s in srcs)
     stale = force or any(

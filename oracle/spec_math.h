@@ -39,6 +39,11 @@ static inline real sp_sqrt(real x) {
  * rather than a flush because one v_max is cheaper than a compare and a select.) */
 static inline real sp_sqrt_floor(real x) { return sp_sqrt(x < R(1e-30) ? R(1e-30) : x); }
 static inline real sp_abs(real x) { return sizeof(real) == 4 ? (real)__builtin_fabsf((float)x) : (real)__builtin_fabs((double)x); }
+/* |mag| with the SIGN BIT of sgn (so -0.0 counts as negative): one bit select on the GPU, no compare */
+static inline real sp_copysign(real mag, real sgn) {
+  return sizeof(real) == 4 ? (real)__builtin_copysignf((float)mag, (float)sgn)
+                           : (real)__builtin_copysign((double)mag, (double)sgn);
+}
 static inline real sp_min(real a, real b) { return a < b ? a : b; }
 static inline real sp_max(real a, real b) { return a > b ? a : b; }
 static inline real sp_clip(real v, real lo, real hi) { return v < lo ? lo : (v > hi ? hi : v); }
@@ -178,7 +183,7 @@ static inline real sp_angle_unit(real s, real c) {
   real r = sp_fma(p * z, u, u);
   if (swap) r = R(1.57079632679489661923) - r;
   if (c < R(0)) r = R(3.14159265358979323846) - r;
-  return s < R(0) ? -r : r;
+  return sp_copysign(r, s); /* the SIGN BIT of s (r >= 0): one bit select on the GPU */
 }
 static inline real sp_asin(real v) { /* |v| <= 1 */
   real c2 = sp_fma(-v, v, R(1));

@@ -43,8 +43,8 @@ def count(targs):
             f.write(f'#include "{csrc}/{hdr}"\ntemplate __global__ void mbd::{kern}<{targs}>(mbd::RolloutParams);\n')
         out = os.path.join(td, "k.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                        "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", "-S", "--cuda-device-only", src,
-                        "-o", out], check=True, capture_output=True)
+                        "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", *os.environ.get("MBD_COUNT_DEFS", "").split(),
+                        "-S", "--cuda-device-only", src, "-o", out], check=True, capture_output=True)
         body = open(out).read().split("\n")
     start = [i for i, l in enumerate(body) if re.match(r"^_ZN3mbd\d+rollout_(planar_)?kernel.*:", l)][0]
     end = [i for i, l in enumerate(body) if i > start and ".Lfunc_end" in l][0]
@@ -67,7 +67,8 @@ def count(targs):
     # square root of the quaternion renormalisation — jumping back into the loop, and the small gather loops)
     outer = max(loops, key=lambda t: len(t[2]))
     inner = [t for t in loops if t[0] > outer[0] and t[1] < outer[1] and len(t[2]) <= len(outer[2]) - 40]
-    best = max(inner, key=lambda t: len(t[2]))[2]
+    bt = max(inner, key=lambda t: len(t[2]))
+    best, loop_text = bt[2], body[bt[0]:bt[1] + 1]
     c = collections.Counter(best)
     flops = 0
     for k, v in c.items():
@@ -81,13 +82,21 @@ def count(targs):
             flops += v
     vg = re.search(r"; NumVgprs:\s+(\d+)", meta)
     sc = re.search(r"; ScratchSize:\s+(\d+)", meta)
-    res = {"template_args": targs, "instructions_per_substep": len(best),
+    # issue slots of a lone wavefront per SIMD (tools/probes/probe_issue.hip): one per instruction, one more for a VALU
+    # compare and for a transcendental, N more for an "s_nop N" (a wait state is a whole 4-cycle slot)
+    nops = [int(x.split()[1]) for x in loop_text if x.strip().startswith("s_nop")]
+    slots = len(best) + sum(v for k, v in c.items() if k.startswith("v_cmp")) + sum(nops) + sum(
+        v for k, v in c.items() if k.startswith(("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_")))
+    res = {"template_args": targs, "instructions_per_substep": len(best), "issue_slots_estimate": slots,
            "valu_per_substep": sum(v for k, v in c.items() if k.startswith("v_")),
            "lds_instr_per_substep": sum(v for k, v in c.items() if k.startswith("ds_")),
            "dpp_per_substep": sum(v for k, v in c.items() if "dpp" in k),
            "s_nop_per_substep": c.get("s_nop", 0), "s_waitcnt_per_substep": c.get("s_waitcnt", 0),
            "fp32_flops_per_lane_substep": flops, "vgpr": int(vg.group(1)) if vg else None,
            "scratch_bytes": int(sc.group(1)) if sc else None}
+    if os.environ.get("MBD_COUNT_DUMP"):  # the substep loop's ISA, for reading
+        with open(os.environ["MBD_COUNT_DUMP"], "w") as f:
+            f.write("\n".join(loop_text))
     return res, c
 
 
