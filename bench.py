@@ -257,11 +257,12 @@ def main():
                 keys = _capi.prng_split(st["rng"], 2)
             st["rng"], ks = keys[0], _capi.key_array(keys[1])
             i, Yb = st["i"], st["Ybar"]
-            _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Yb.data_ptr(), local[0].data_ptr(),
-                                                    local[1].data_ptr() if DEMO else None, stream))
-            # the next step's noise depends on its key only: generated behind this rollout (a hint; same results)
+            # the next step's noise depends on its key only: declared now, generated beside this rollout (a hint; same
+            # results)
             st["keys"] = _capi.prng_split(st["rng"], 2)
             _capi.check(lib.mbd_plan_prefetch_noise(plan.h, _capi.key_array(st["keys"][1]), stream))
+            _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Yb.data_ptr(), local[0].data_ptr(),
+                                                    local[1].data_ptr() if DEMO else None, stream))
             if distributed and backend == "nccl":
                 dist.all_gather_into_tensor(gath, local)  # the ONE collective of a diffusion step (RCCL/xGMI)
                 src = gath.view(world, rows, N_local).permute(1, 0, 2).reshape(rows, N_total) if rows > 1 else \
@@ -294,7 +295,13 @@ def main():
             for _ in range(args.warmup):
                 step(read_back)
             fence()
-            plan.enable_timing(True)
+            # The rollout kernel's duration comes from HIP events around every launch on the launch stream.  Two event
+            # records per step cost the stream ~7.5 us (profiles/r02_timeline.md: ~5.5 us of idle queue per record),
+            # 1.2 % of a step — so they bracket the launches of the K steps of the value_async leg, and the headline
+            # leg (value: the K steps with the per-step host read) runs uninstrumented.  MBD_BENCH_EVENTS=all|none
+            # moves them (experiments).
+            ev_mode = os.environ.get("MBD_BENCH_EVENTS", "async")
+            plan.enable_timing(ev_mode == "all" or (ev_mode == "async" and not read_back))
             t0 = time.perf_counter()
             for _ in range(args.steps):
                 step(read_back)
@@ -341,7 +348,9 @@ def main():
             return (args.steps / el) * (N_total / N_CFG if mode == "weak" else 1.0), 1e3 * el / args.steps
 
         mode = args.scaling
-        (el_s, kern_ms, kern_n), (el_a, kern_ms_a, _) = res[mode]
+        (el_s, kern_ms_s, kern_n_s), (el_a, kern_ms, kern_n) = res[mode]
+        if kern_n == 0:  # MBD_BENCH_EVENTS=all / none
+            kern_ms, kern_n = kern_ms_s, kern_n_s
         N_total, N_local = runs.get(mode, runs["strong"])
         value, ms_sync = rate(mode, "sync")
         value_async, ms_async = rate(mode, "async")
@@ -364,7 +373,9 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": cfg["kernel"], "kernel_avg_ms": kern_ms,
-                         "kernel_launches": kern_n, "algorithmic_bytes_per_launch": balg,
+                         "kernel_launches": kern_n, "kernel_timing": "HIP events around every rollout launch of the "
+                         "value_async leg (same K steps; the value leg runs without them: two event records cost a "
+                         "step ~7.5 us)", "algorithmic_bytes_per_launch": balg,
                          "note": "state stays in VGPRs for all H*n_frames substeps: the kernel is bound by "
                                  "dependent FP32 VALU issue, not HBM (DESIGN.md §Roofline)"},
             "final_reward": final,

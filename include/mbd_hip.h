@@ -267,16 +267,20 @@ int mbd_plan_set_state0(mbd_plan* plan, const float* state0);
 
 /* ---- one reverse-diffusion step, split at the (only) exchange point so that N can be sharded ---- */
 /* phase 1 (mbd_planner.py:103-110): eps -> Y0s = clip(eps*sigma_i + Ybar_i) for the local shard,
- * rollout, rews = mean_H(rewss) [+ demo log-densities].  d_Ybar_i [H][Nu] (device, read), key_sample
+ * rollout, rews = mean_H(rewss) [+ demo log-densities].  (MBD plans on rigid-body envs keep eps and form the
+ * candidate values where they are consumed — the rollout's action fetch, the weighted mean, mbd_plan_peek — with the
+ * same two roundings; d_Ybar_i must stay unchanged until phase 2 of the step has run.)  d_Ybar_i [H][Nu] (device, read), key_sample
  * is Y0s_rng of (:103).  Writes d_rews_local [shard_count] and, with demos, d_logpd_local
  * [shard_count] (else may be NULL).  async on stream. */
 int mbd_plan_sample_rollout(mbd_plan* plan, int i, const uint32_t key_sample[2],
                             const float* d_Ybar_i, float* d_rews_local, float* d_logpd_local,
                             void* stream);
-/* Optional hint between phase 1 and phase 2: the normals of the NEXT diffusion step (jax.random.normal(Y0s_rng, ...),
- * mbd_planner.py:104 — they depend on that step's key only) are generated on the plan's second stream while the
- * current rollout runs; the next mbd_plan_sample_rollout uses them when its key_sample equals key_next and samples as
- * usual otherwise.  Results are bit-identical with and without the hint.  Does nothing for small plans. */
+/* Optional hint BEFORE phase 1: declares key_next, the Y0s_rng of the diffusion step AFTER the one the next
+ * mbd_plan_sample_rollout runs.  Its normals (jax.random.normal(Y0s_rng, ...), mbd_planner.py:104 — they depend on that
+ * step's key only) are then generated beside that rollout: in spare workgroups of the rollout launch itself when it
+ * leaves CUs idle, on the plan's second stream otherwise; the declared step finds them ready when its key_sample
+ * equals key_next and generates its own otherwise.  Results are bit-identical with and without the hint.  Plans that
+ * materialise Y0s (car2d, path-integral updates) ignore it.  `stream` is unused (kept for ABI stability). */
 int mbd_plan_prefetch_noise(mbd_plan* plan, const uint32_t key_next[2], void* stream);
 /* phase 2 (mbd_planner.py:111-135): from ALL N rewards (after the all-gather) standardise, demo
  * blend, softmax, weighted mean over all N candidates (noise regenerated from the counter-based PRNG,

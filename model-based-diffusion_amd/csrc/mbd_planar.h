@@ -68,6 +68,10 @@ template <int LPS, int MAXCOL, int D0 = 0, int D1 = 0>
 __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   constexpr bool DPP = D0 != 0;
   constexpr int NSLOT = DPP ? (D1 != 0 ? 2 : 1) : kMaxChildren;
+  if ((int)blockIdx.x >= P.roll_blocks) {  // the next step's normals, on CUs the rollout leaves idle (mbd_kernels.h)
+    noise_blocks(P);
+    return;
+  }
   const mbd_model_t* __restrict__ M = P.model;
   const int lane = threadIdx.x & 63;
   const int base = lane & ~(LPS - 1);
@@ -209,24 +213,58 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   if (!link_ok) { px = pz = 0.0f; qw = 1.0f; qy = 0.0f; vx = vz = om = 0.0f; }
 
   const float* u_row = P.us + (size_t)b * H * Nu;
+  // lazy candidates (wave-uniform; RolloutParams): u_row holds normals, the action is clip(eps * sigma + Ybar_i, -1, 1)
+  // (branch-free, like rollout_kernel: unconditional Ybar loads — from P.us itself, ignored, when not lazy — and selects)
+  const bool lazy = P.ybar != nullptr;
+  const float* __restrict__ yb_row = lazy ? P.ybar : P.us;
+  const float sigma = P.sigma;
+  auto cand = [&](float e, float yb) {
+    const float c = fclip(e * sigma + yb, -1.0f, 1.0f);
+    return lazy ? c : e;
+  };
   auto load_u = [&](int t, int a) { return u_row[(size_t)t * Nu + (a >= 0 ? a : 0)]; };
+  auto load_y = [&](int t, int a) { return yb_row[(size_t)t * Nu + (a >= 0 ? a : 0)]; };
   float u_rot = load_u(0, act_rot), u_sl0 = load_u(0, act_sl[0]), u_sl1 = load_u(0, act_sl[1]);
+  float y_rot = load_y(0, act_rot), y_sl0 = load_y(0, act_sl[0]), y_sl1 = load_y(0, act_sl[1]);
+  // control cost (halfcheetah): the whole action row of the next control step travels with the other prefetched
+  // actions (mbd_kernels.h: fetched where it is used, its Nu dependent round trips were 10 % of the rollout)
+  constexpr int KCC = 8;
+  const bool want_cc = rkind == MBD_REW_HALFCHEETAH;  // wave-uniform
+  float cc_u[KCC], cc_y[KCC], ccn_u[KCC], ccn_y[KCC];
+  auto load_row = [&](int t, float (&ru)[KCC], float (&ry)[KCC]) {
+#pragma unroll
+    for (int k = 0; k < KCC; ++k) {
+      ru[k] = u_row[(size_t)t * Nu + (k < Nu ? k : 0)];
+      ry[k] = yb_row[(size_t)t * Nu + (k < Nu ? k : 0)];
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < KCC; ++k) { cc_u[k] = cc_y[k] = ccn_u[k] = ccn_y[k] = 0.0f; }
+  if (want_cc) load_row(0, cc_u, cc_y);
   float rew_sum = 0.0f;
 
   for (int t = 0; t < H; ++t) {
+    u_rot = cand(u_rot, y_rot); u_sl0 = cand(u_sl0, y_sl0); u_sl1 = cand(u_sl1, y_sl1);
     const float tau0 = fclip(act_rot >= 0 ? u_rot : 0.0f, alo_rot, ahi_rot) * gear_rot;
     float tau_sl[2];
     tau_sl[0] = fclip(act_sl[0] >= 0 ? u_sl0 : 0.0f, alo_sl[0], ahi_sl[0]) * gear_sl[0];
     tau_sl[1] = fclip(act_sl[1] >= 0 ? u_sl1 : 0.0f, alo_sl[1], ahi_sl[1]) * gear_sl[1];
     float ctrl_cost = 0.0f;
-    if (rkind == MBD_REW_HALFCHEETAH && root_lane) {
-      for (int a = 0; a < Nu; ++a) {
-        const float ua = u_row[(size_t)t * Nu + a];
+    if (want_cc) {
+#pragma unroll
+      for (int k = 0; k < KCC; ++k) {
+        const float ua = cand(cc_u[k], cc_y[k]);
+        ctrl_cost = k < Nu ? ctrl_cost + ua * ua : ctrl_cost;
+      }
+      for (int a = KCC; a < Nu; ++a) {
+        const float ua = cand(u_row[(size_t)t * Nu + a], yb_row[(size_t)t * Nu + a]);
         ctrl_cost = ctrl_cost + ua * ua;
       }
     }
     const int tn = t + 1 < H ? t + 1 : t;  // the next control step's actions, in flight across the substeps
     const float un_rot = load_u(tn, act_rot), un_sl0 = load_u(tn, act_sl[0]), un_sl1 = load_u(tn, act_sl[1]);
+    const float yn_rot = load_y(tn, act_rot), yn_sl0 = load_y(tn, act_sl[0]), yn_sl1 = load_y(tn, act_sl[1]);
+    if (want_cc) load_row(tn, ccn_u, ccn_y);
     __builtin_amdgcn_sched_barrier(0);
     float o0x, o0z;
     {
@@ -481,6 +519,9 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       if (b_ok && P.rewss) P.rewss[(size_t)b * H + t] = rew;
     }
     u_rot = un_rot; u_sl0 = un_sl0; u_sl1 = un_sl1;
+    y_rot = yn_rot; y_sl0 = yn_sl0; y_sl1 = yn_sl1;
+#pragma unroll
+    for (int k = 0; k < KCC; ++k) { cc_u[k] = ccn_u[k]; cc_y[k] = ccn_y[k]; }
   }  // control steps
   if (root_lane && b_ok && P.rews) P.rews[b] = rew_sum / (float)H;
   if (P.state_final && link_ok && b_ok) {

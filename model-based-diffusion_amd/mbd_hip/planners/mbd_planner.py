@@ -234,11 +234,11 @@ def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bo
         rng, ks = keys[0], _capi.key_array(keys[1])
         if ev:
             ev[0].record()
-        _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Ybar.data_ptr(), local[0].data_ptr(),
-                                                local[1].data_ptr() if demo else None, stream))
-        keys = _capi.prng_split(rng, 2, impl)  # the next step's split: its noise is generated behind this rollout
+        keys = _capi.prng_split(rng, 2, impl)  # the next step's split: its normals are generated beside this rollout
         if i > 1:
             _capi.check(lib.mbd_plan_prefetch_noise(plan.h, _capi.key_array(keys[1]), stream))
+        _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Ybar.data_ptr(), local[0].data_ptr(),
+                                                local[1].data_ptr() if demo else None, stream))
         if ev:
             ev[1].record()
         allv = exchange_rewards(local, world, group)

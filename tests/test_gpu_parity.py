@@ -714,13 +714,19 @@ def test_progress_callback_reads_every_step(gpu):
     assert np.array_equal(d1["mu_0ts"], d2["mu_0ts"]) and r1 == r2
 
 
+@pytest.mark.parametrize("mode", ["fused", "aux"])
 @pytest.mark.parametrize("impl", [1, 0])
-def test_noise_prefetch_is_bit_identical(gpu, impl, monkeypatch):
-    """mbd_plan_prefetch_noise (the next step's normals generated behind the current rollout, then only shifted) is a
-    HINT: a plan big enough to use it (humanoidrun N=2048: 1.74 M noise elements) run through mbd_plan_run — which
-    prefetches — must equal, bit for bit, the same plan stepped by hand through sample_rollout / score_update without
-    any prefetch call; and a prefetch with a key that is NOT used next must be ignored.  Both threefry layouts."""
+def test_noise_prefetch_is_bit_identical(gpu, impl, mode, monkeypatch):
+    """mbd_plan_prefetch_noise (the NEXT step's normals generated beside the current rollout — in spare workgroups of
+    the rollout launch ("fused"), or on the plan's second stream when the rollout fills the chip ("aux", forced here
+    by MBD_NO_FUSED_NOISE) — and the candidates formed lazily at the rollout's action fetch and in the weighted mean)
+    is a HINT: a plan run through mbd_plan_run — which declares every next key — must equal, bit for bit, (a) the same
+    plan stepped by hand through sample_rollout / score_update without any declaration, where a declaration of a key
+    that is NOT used next must be ignored, and (b) the same plan with materialised candidates (MBD_NO_LAZY: the
+    sampler writes Y0s, rollout and weighted mean read it).  Both threefry layouts."""
     monkeypatch.setenv("MBD_THREEFRY_PARTITIONABLE", str(impl))
+    if mode == "aux":
+        monkeypatch.setenv("MBD_NO_FUSED_NOISE", "1")
     import torch
     from mbd_hip.envs import get_env
     from mbd_hip.planners.mbd_planner import Args, Plan
@@ -733,7 +739,17 @@ def test_noise_prefetch_is_bit_identical(gpu, impl, monkeypatch):
     p1 = Plan(env, args)
     p1.set_state0(st)
     mu1, rm1, rf1, _ = p1.run(key)
+    Y1, rewss1, w1 = p1.peek()
     p1.close()
+    monkeypatch.setenv("MBD_NO_LAZY", "1")
+    p0 = Plan(env, args)
+    monkeypatch.delenv("MBD_NO_LAZY")
+    p0.set_state0(st)
+    mu0, rm0, rf0, _ = p0.run(key)
+    Y0, rewss0, w0 = p0.peek()
+    p0.close()
+    assert np.array_equal(mu0, mu1) and np.array_equal(rm0, rm1) and rf0 == rf1
+    assert np.array_equal(Y0, Y1) and np.array_equal(rewss0, rewss1) and np.array_equal(w0, w1)
     p2 = Plan(env, args)
     p2.set_state0(st)
     HNu = H * 17
@@ -743,8 +759,10 @@ def test_noise_prefetch_is_bit_identical(gpu, impl, monkeypatch):
     for i in range(Nd - 1, 0, -1):
         keys = gpu.prng_split(rng, 2, impl)
         rng, ks = keys[0], gpu.key_array(keys[1])
-        if i == 3:  # a prefetch for a key nobody will ask for: must be ignored
+        if i == 3:  # a declaration of a key nobody will ask for: generated, then ignored
             gpu.check(p2.lib.mbd_plan_prefetch_noise(p2.h, gpu.key_array(gpu.prng_key(12345)), None))
+        if i == 2:  # the current step's own key declared as "next": nothing to prepare
+            gpu.check(p2.lib.mbd_plan_prefetch_noise(p2.h, ks, None))
         loc, out, rm = torch.zeros(N, device="cuda"), torch.zeros(HNu, device="cuda"), torch.zeros(1, device="cuda")
         gpu.check(p2.lib.mbd_plan_sample_rollout(p2.h, i, ks, Ybar.data_ptr(), loc.data_ptr(), None, None))
         gpu.check(p2.lib.mbd_plan_score_update(p2.h, i, ks, Ybar.data_ptr(), loc.data_ptr(), None, out.data_ptr(),

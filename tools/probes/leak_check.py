@@ -12,7 +12,7 @@ for it in range(60):
     p.set_state0(env.reset(_capi.prng_key(it)))
     Y = torch.zeros(850, device="cuda"); loc = torch.zeros(512, device="cuda")
     _capi.check(p.lib.mbd_plan_sample_rollout(p.h, 5, _capi.key_array(_capi.prng_key(1)), Y.data_ptr(), loc.data_ptr(), None, None))
-    _capi.check(p.lib.mbd_plan_prefetch_noise(p.h, _capi.key_array(_capi.prng_key(2)), None))  # (allocates the noise buffer)
+    _capi.check(p.lib.mbd_plan_prefetch_noise(p.h, _capi.key_array(_capi.prng_key(2)), None))  # (declared after the fact: the next step generates its own)
     _capi.check(p.lib.mbd_plan_sample_rollout(p.h, 4, _capi.key_array(_capi.prng_key(2)), Y.data_ptr(), loc.data_ptr(), None, None))
     torch.cuda.synchronize()
     p.close(); env.close() if hasattr(env, "close") else None
