@@ -198,31 +198,26 @@ MBD_HD float atan2_(float y, float x) {
   return y < 0.0f ? -r : r;
 }
 // ---- the solver's division -------------------------------------------------------------------------------
-// numerators below 1e-28 are flushed to zero; with that, and denominators in [1e-20, 1e10], the bare
-// reciprocal + FMA refinement below rounds exactly like IEEE division (it is the hardware expansion of '/'
-// minus v_div_scale / v_div_fixup, which only act on extreme exponents) — checked on 1e9 samples by
-// tools/probes/probe_div.hip.  8 VALU for one quotient, 9 for a pair (packed FMAs).
-__device__ __forceinline__ float div_(float n, float d) {
-  n = fabs_(n) < 1e-28f ? 0.0f : n;
+// numerators below 1e-28 are flushed to zero (or clamped there when non-negative by construction); with that, and
+// denominators in [1e-20, 1e10], the sequence below rounds exactly like IEEE division:
+//   r = rcp(d) + one Newton step  is the CORRECTLY ROUNDED reciprocal for every float32 in [1e-20, 1e20] (exhaustive,
+//                                 tools/probes/probe_rcp.hip);
+//   q = n r;  e = n - d q (fma);  q' = q + e r (fma)  is then the correctly rounded quotient (Markstein's theorem: a
+//                                 correctly rounded reciprocal and a faithful q need ONE residual step; checked on
+//                                 2.6e10 random pairs with full random mantissas and on the hard denominators —
+//                                 mantissa all ones / all zeros — by tools/probes/probe_short.hip, 0 mismatches).
+// It is the hardware expansion of '/' minus v_div_scale / v_div_fixup (which only act on extreme exponents) and minus
+// its second residual step: 6 VALU for one quotient, as many for a pair (packed FMAs).
+// 1.0f / d for d in [1e-20, 1e20]: the reciprocal itself — 3 VALU, same value as div_(1.0f, d)
+__device__ __forceinline__ float rcp_exact(float d) {
   float r = __builtin_amdgcn_rcpf(d);
   float e = ffma(-d, r, 1.0f);
-  r = ffma(e, r, r);
-  float q = n * r;
-  e = ffma(-d, q, n);
-  q = ffma(e, r, q);
-  e = ffma(-d, q, n);
-  return ffma(e, r, q);
+  return ffma(e, r, r);
 }
-// numerators that are non-negative by construction: clamped from below at 1e-28 (one v_max) instead of flushed
-// (a compare + a select: three issue slots for a lone wave)
 __device__ __forceinline__ float div_core_(float n, float d) {
-  float r = __builtin_amdgcn_rcpf(d);
-  float e = ffma(-d, r, 1.0f);
-  r = ffma(e, r, r);
+  float r = rcp_exact(d);
   float q = n * r;
-  e = ffma(-d, q, n);
-  q = ffma(e, r, q);
-  e = ffma(-d, q, n);
+  float e = ffma(-d, q, n);
   return ffma(e, r, q);
 }
 __device__ __forceinline__ f2 div2_core_(f2 n, f2 d) {
@@ -231,10 +226,11 @@ __device__ __forceinline__ f2 div2_core_(f2 n, f2 d) {
   r = fma2(e, r, r);
   f2 q = n * r;
   e = fma2(-d, q, n);
-  q = fma2(e, r, q);
-  e = fma2(-d, q, n);
   return fma2(e, r, q);
 }
+__device__ __forceinline__ float div_(float n, float d) { return div_core_(fabs_(n) < 1e-28f ? 0.0f : n, d); }
+// numerators that are non-negative by construction: clamped from below at 1e-28 (one v_max) instead of flushed
+// (a compare + a select: three issue slots for a lone wave)
 __device__ __forceinline__ float div_pos_(float n, float d) { return div_core_(fmax_(n, 1e-28f), d); }
 __device__ __forceinline__ f2 div2_pos_(f2 n, f2 d) { return div2_core_(mk2(fmax_(n.x, 1e-28f), fmax_(n.y, 1e-28f)), d); }
 // (signed numerator in the low half, non-negative one in the high half)
@@ -242,33 +238,23 @@ __device__ __forceinline__ f2 div2_sp_(f2 n, f2 d) {
   return div2_core_(mk2(fabs_(n.x) < 1e-28f ? 0.0f : n.x, fmax_(n.y, 1e-28f)), d);
 }
 __device__ __forceinline__ f2 div2_(f2 n, f2 d) {
-  n = mk2(fabs_(n.x) < 1e-28f ? 0.0f : n.x, fabs_(n.y) < 1e-28f ? 0.0f : n.y);
-  f2 r = mk2(__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y));
-  f2 e = fma2(-d, r, mk2(1.0f, 1.0f));
-  r = fma2(e, r, r);
-  f2 q = n * r;
-  e = fma2(-d, q, n);
-  q = fma2(e, r, q);
-  e = fma2(-d, q, n);
-  return fma2(e, r, q);
+  return div2_core_(mk2(fabs_(n.x) < 1e-28f ? 0.0f : n.x, fabs_(n.y) < 1e-28f ? 0.0f : n.y), d);
 }
 
 // ---- the solver's square root -----------------------------------------------------------------------------
-// the argument is clamped from below at 1e-30 (one v_max); then reciprocal square root + FMA refinement,
-// bit-identical to the correctly rounded sqrtf on every float32 in [1e-30, FLT_MAX] (exhaustive:
-// tools/probes/probe_sqrt.hip).  9 VALU instead of the 16 of the compiler's expansion, which also scales denormals.
+// the argument is clamped from below at 1e-30 (one v_max); then the reciprocal square root and ONE correction:
+// g = x rsq(x), s = g + (x - g g)(rsq(x) / 2) — bit-identical to the correctly rounded sqrtf on every float32 in
+// [1e-30, FLT_MAX] (exhaustive: tools/probes/probe_short.hip; so is the longer form with a refined g,
+// tools/probes/probe_sqrt.hip).  6 VALU instead of the 16 of the compiler's expansion, which also scales denormals.
 __device__ __forceinline__ float sqrt_floor(float x) {
   x = fmax_(x, 1e-30f);
   float r = __builtin_amdgcn_rsqf(x);
   float g = x * r, h = 0.5f * r;
-  float e = ffma(-h, g, 0.5f);
-  g = ffma(g, e, g);
-  h = ffma(h, e, h);
   float d = ffma(-g, g, x);
   return ffma(d, h, g);
 }
 
-// two packed divisions as interleaved chains (same arithmetic as two div2_ calls)
+// two packed divisions as interleaved chains (same arithmetic as two div2_pos_ calls)
 __device__ __forceinline__ void div2x2_(f2 na, f2 da, f2 nb, f2 db, f2& qa_out, f2& qb_out) {
   na = mk2(fmax_(na.x, 1e-28f), fmax_(na.y, 1e-28f));  // (all four are squared lengths)
   nb = mk2(fmax_(nb.x, 1e-28f), fmax_(nb.y, 1e-28f));
@@ -278,8 +264,6 @@ __device__ __forceinline__ void div2x2_(f2 na, f2 da, f2 nb, f2 db, f2& qa_out, 
   f2 ea = fma2(-da, ra, one), eb = fma2(-db, rb, one);
   ra = fma2(ea, ra, ra); rb = fma2(eb, rb, rb);
   f2 qa = na * ra, qb = nb * rb;
-  ea = fma2(-da, qa, na); eb = fma2(-db, qb, nb);
-  qa = fma2(ea, ra, qa); qb = fma2(eb, rb, qb);
   ea = fma2(-da, qa, na); eb = fma2(-db, qb, nb);
   qa_out = fma2(ea, ra, qa); qb_out = fma2(eb, rb, qb);
 }
