@@ -5,7 +5,7 @@ R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for m in ${MODES:-lazy nolazy}; do
   E="X=1"; [[ $m == nolazy* ]] && E="MBD_NO_LAZY=1"; [[ $m == aux* ]] && E="MBD_NO_FUSED_NOISE=1"
-  [[ $m == *-noev ]] && E="$E MBD_BENCH_EVENTS=none"
+  [[ $m == *-noev ]] && E="$E MBD_BENCH_EVENTS=none"; [[ $m == *-ev ]] && E="$E MBD_BENCH_EVENTS=all"
   [[ $m == nopf* ]] && E="$E MBD_NO_PREFETCH=1"
   [[ $m == nolds* ]] && E="$E MBD_LDS_RESERVE=0"
   env $E rocprofv3 --kernel-trace -d $OUT/tl_$m -o t -- python $R/bench.py --config ${CFG:-metric} --no-cpu-baseline --no-final-reward --steps 30 --warmup 5 > $OUT/tl_$m.log 2>&1
