@@ -4,6 +4,7 @@ The numerical contract makes every comparison BIT-EXACT (np.array_equal), far in
 tolerance the north star asks for — which is the only way to get a meaningful comparison through 350
 chaotic contact-rich substeps (tests/test_oracle_physics.py::test_chaos_amplification)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -800,3 +801,26 @@ def test_general_3d_kernels_on_planar_models(gpu, orc_omp, name, B, no_dpp, monk
     ref = oe.rollout(np.asarray(st.pipeline_state, np.float32), us)
     assert np.isfinite(got).all()
     assert np.array_equal(got, ref), f"{name}: max |d| = {np.abs(got - ref).max()}"
+
+
+def test_short_exact_sequences(gpu):
+    """The value-preserving shortcuts of csrc/mbd_math.h, on the device that runs them: rcp + one Newton
+    step is the correctly rounded reciprocal for EVERY float32 in [1e-20, 1e20]; with it ONE residual step gives the
+    correctly rounded quotient (2.6e10 random pairs with full random mantissas + the hard denominators); rsq + one
+    correction is the correctly rounded square root for EVERY float32 in [1e-30, FLT_MAX].  The probes are standalone
+    HIP programs built by __graft_entry__.build(); the controls (bare rcp / rsq products) must mismatch."""
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([os.path.join(root, "tools", "probes", "probe_rcp")], capture_output=True, text=True,
+                         timeout=300, check=True).stdout
+    rows = re.findall(r"^\s+([ABC]) .*?(\d+) mismatches", out, re.M)
+    assert [r[0] for r in rows] == ["A", "B", "C"] and all(int(r[1]) == 0 for r in rows), out
+    assert "1114674149 checked" in out
+    out = subprocess.run([os.path.join(root, "tools", "probes", "probe_short")], capture_output=True, text=True,
+                         timeout=600, check=True).stdout
+    div = re.findall(r"^div5 .*mismatches (\d+) of (\d+) \(control n\*rcp\(d\): (\d+)\)", out, re.M)
+    assert len(div) == 6 and all(int(m) == 0 and int(n) == 2048 * 256 * 8192 and int(c) > 0 for m, n, c in div), out
+    sq = re.findall(r"^(sqrtA|sqrtB|control).*?(\d+) mismatches of (\d+)", out, re.M)
+    assert len(sq) == 3 and int(sq[0][1]) == 0 and int(sq[1][1]) == 0 and int(sq[2][1]) > 0, out
+    assert all(int(x[2]) == 1910357408 for x in sq), out
