@@ -248,43 +248,54 @@ def main():
         host = HostProgress(1, dev)
         st = {"rng": np.asarray(rng_exp, np.uint32), "i": ND - 1, "Ybar": Ybar, "Ynext": Ynext}
 
-        def step(read_back):
-            if st["i"] < 1:  # start the next plan: YN = zeros, fresh schedule position
+        p_loc0, p_loc1 = local[0].data_ptr(), (local[1].data_ptr() if DEMO else None)
+        p_rewmean = rew_mean.data_ptr()
+
+        def prepare():
+            """Everything the next step needs that does not depend on the GPU — the key chain, the declaration of the
+            step after it (mbd_plan_prefetch_noise) — done while the device runs the current step, BEFORE the host
+            waits for its mean reward: the wait is then followed by the rollout launch and nothing else."""
+            if st["i"] < 1:  # start the next plan: YN = zeros, fresh schedule position (enqueued behind the last update)
                 st["i"] = ND - 1
                 st["Ybar"].zero_()
             keys = st.get("keys")
             if keys is None:
                 keys = _capi.prng_split(st["rng"], 2)
-            st["rng"], ks = keys[0], _capi.key_array(keys[1])
-            i, Yb = st["i"], st["Ybar"]
-            # the next step's noise depends on its key only: declared now, generated beside this rollout (a hint; same
-            # results)
+            st["rng"], st["ks"] = keys[0], _capi.key_array(keys[1])
+            # the step after the next: its noise depends on its key only — declared now, generated beside the next
+            # rollout (a hint; same results)
             st["keys"] = _capi.prng_split(st["rng"], 2)
             _capi.check(lib.mbd_plan_prefetch_noise(plan.h, _capi.key_array(st["keys"][1]), stream))
-            _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Yb.data_ptr(), local[0].data_ptr(),
-                                                    local[1].data_ptr() if DEMO else None, stream))
+            st["pY"], st["pYn"] = st["Ybar"].data_ptr(), st["Ynext"].data_ptr()
+
+        def step(read_back):
+            i, ks, pY, pYn = st["i"], st["ks"], st["pY"], st["pYn"]
+            _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, pY, p_loc0, p_loc1, stream))
             if distributed and backend == "nccl":
                 dist.all_gather_into_tensor(gath, local)  # the ONE collective of a diffusion step (RCCL/xGMI)
                 src = gath.view(world, rows, N_local).permute(1, 0, 2).reshape(rows, N_total) if rows > 1 else \
                     gath.view(1, N_total)
                 src = src.contiguous() if rows > 1 else src
+                p_s0, p_s1 = src[0].data_ptr(), (src[1].data_ptr() if DEMO else None)
             elif distributed:  # gloo dry run: stage through the host
                 staged = torch.empty((world * rows, N_local), dtype=torch.float32)
                 dist.all_gather_into_tensor(staged, local.cpu())
                 allv.copy_(staged.view(world, rows, N_local).permute(1, 0, 2).reshape(rows, N_total))
-                src = allv
+                p_s0, p_s1 = allv[0].data_ptr(), (allv[1].data_ptr() if DEMO else None)
             else:
-                src = local
+                p_s0, p_s1 = p_loc0, p_loc1
             if read_back:
                 host.reset(0)
-            _capi.check(lib.mbd_plan_score_update(plan.h, i, ks, Yb.data_ptr(), src[0].data_ptr(),
-                                                  src[1].data_ptr() if DEMO else None, st["Ynext"].data_ptr(),
-                                                  host.ptr(0) if read_back else rew_mean.data_ptr(), stream))
+            _capi.check(lib.mbd_plan_score_update(plan.h, i, ks, pY, p_s0, p_s1, pYn,
+                                                  host.ptr(0) if read_back else p_rewmean, stream))
             st["Ybar"], st["Ynext"] = st["Ynext"], st["Ybar"]
             st["i"] = i - 1
+            prepare()
             if read_back:  # pbar.set_postfix({"rew": f"{rew:.2e}"}) (mbd_planner.py:147): the host has the step's
                 return host.wait(0)  # mean reward in hand before it dispatches the next step
             return None
+
+        prepare()
 
         def fence():
             if distributed:

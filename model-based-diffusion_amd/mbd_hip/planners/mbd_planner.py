@@ -229,16 +229,20 @@ def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bo
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if phase_times is not None else None
     acc = [0.0, 0.0, 0.0]
     host = HostProgress(plan.Nd - 1, dev) if (sync_every_step or progress is not None) else None
-    keys = _capi.prng_split(rng, 2, impl)  # rng, Y0s_rng = split(rng)  (mbd_planner.py:103)
+    # Host work that does not depend on the GPU — the key chain (rng, Y0s_rng = split(rng), mbd_planner.py:103) and the
+    # declaration of the FOLLOWING step's key (its normals are generated beside this step's rollout) — is done while
+    # the device runs the previous step, before the host waits for that step's mean reward: the wait is followed by
+    # the rollout launch and nothing else.
+    keys = _capi.prng_split(rng, 2, impl)
+    rng, ks = keys[0], _capi.key_array(keys[1])
+    keys = _capi.prng_split(rng, 2, impl)
+    if plan.Nd - 1 > 1:
+        _capi.check(lib.mbd_plan_prefetch_noise(plan.h, _capi.key_array(keys[1]), stream))
+    p_loc0, p_loc1 = local[0].data_ptr(), (local[1].data_ptr() if demo else None)
     for i in range(plan.Nd - 1, 0, -1):
-        rng, ks = keys[0], _capi.key_array(keys[1])
         if ev:
             ev[0].record()
-        keys = _capi.prng_split(rng, 2, impl)  # the next step's split: its normals are generated beside this rollout
-        if i > 1:
-            _capi.check(lib.mbd_plan_prefetch_noise(plan.h, _capi.key_array(keys[1]), stream))
-        _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Ybar.data_ptr(), local[0].data_ptr(),
-                                                local[1].data_ptr() if demo else None, stream))
+        _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Ybar.data_ptr(), p_loc0, p_loc1, stream))
         if ev:
             ev[1].record()
         allv = exchange_rewards(local, world, group)
@@ -253,8 +257,13 @@ def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bo
         if ev:
             ev[3].record()
             ev[3].synchronize()
-            for k in range(3):
-                acc[k] += ev[k].elapsed_time(ev[k + 1])
+            for j in range(3):
+                acc[j] += ev[j].elapsed_time(ev[j + 1])
+        if i > 1:  # the next step's keys, and the declaration of the one after it
+            rng, ks = keys[0], _capi.key_array(keys[1])
+            keys = _capi.prng_split(rng, 2, impl)
+            if i > 2:
+                _capi.check(lib.mbd_plan_prefetch_noise(plan.h, _capi.key_array(keys[1]), stream))
         if host is not None:  # the reference formats the reward every step (:147): one host read per step
             r = host.wait(k)
             if progress is not None:
