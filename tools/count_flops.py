@@ -67,7 +67,10 @@ def count(targs):
     # square root of the quaternion renormalisation — jumping back into the loop, and the small gather loops)
     outer = max(loops, key=lambda t: len(t[2]))
     inner = [t for t in loops if t[0] > outer[0] and t[1] < outer[1] and len(t[2]) <= len(outer[2]) - 40]
-    bt = max(inner, key=lambda t: len(t[2]))
+    # the substep loop touches no global memory (actions are fetched per CONTROL step, rewards stored per control step):
+    # the longest backward-branch region without a global / flat / scratch access
+    nomem = [t for t in loops if not any(x.startswith(("global_", "flat_", "scratch_", "buffer_")) for x in t[2])]
+    bt = max(nomem or inner, key=lambda t: len(t[2]))
     best, loop_text = bt[2], body[bt[0]:bt[1] + 1]
     c = collections.Counter(best)
     flops = 0
