@@ -64,7 +64,11 @@ __device__ __forceinline__ void pl_qupdate(float& w, float& y, float dth) {
 
 // LPS lanes per candidate; D0, D1: DPP layout (lane(parent) = lane(s-th child) + Ds; D0 = 0: ds_bpermute exchange,
 // up to kMaxChildren children); MAXCOL sphere colliders per link (0: the contact stages are compiled out)
-template <int LPS, int MAXCOL, int D0 = 0, int D1 = 0>
+// FL: the model's wave-uniform switches as COMPILE-TIME constants — bit 0: some hinge has a joint spring (any_stiff),
+// bit 1: some slide dof has a finite range (slide_limits), bit 2: elasticity != 0 — or -1: read them at run time.  As
+// run-time flags each is a taken forward branch per substep for the models that lack the feature (every built-in one
+// lacks two or three), and a lone wavefront pays for a taken branch with a refill of its instruction buffer.
+template <int LPS, int MAXCOL, int D0 = 0, int D1 = 0, int FL = -1>
 __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   constexpr bool DPP = D0 != 0;
   constexpr int NSLOT = DPP ? (D1 != 0 ? 2 : 1) : kMaxChildren;
@@ -289,7 +293,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         float rvx = vax.y - vax.x, rvz = vaz.y - vaz.x;
         const float rw = om - Pom;
         float fk = ffma(-damp, sg * rw, tau0);
-        if (P.any_stiff) {  // (wave-uniform) the hinge angle only feeds the joint spring: -0 * ang is an exact zero
+        if (FL >= 0 ? (FL & 1) != 0 : P.any_stiff != 0) {  // (wave-uniform) the hinge angle only feeds the joint spring: -0 * ang is an exact zero
           float wr, yr;
           pl_rel(Pw, Py, qw, qy, wr, yr);
           const float ang = sg * pl_angle(wr, yr);
@@ -345,7 +349,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         f2 lx2 = bc2(Px) * im2, lz2 = bc2(Pz) * im2;                      // (dp_p, dc_p)
         const f2 t2 = pl_cross2(rx, rz, bc2(Px), bc2(Pz)) * iy2;
         f2 th2 = mk2(-t2.x, t2.y);                                         // (dp_th, dc_th)
-        if (P.slide_limits) {  // (wave-uniform)
+        if (FL >= 0 ? (FL & 2) != 0 : P.slide_limits != 0) {  // (wave-uniform)
           const float ex = awx.y - awx.x, ez = awz.y - awz.x;
 #pragma unroll
           for (int j = 0; j < 2; ++j) {
@@ -468,7 +472,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
           const float rcx = cposx[j] - px, rcz = cposz[j] - pz;
           const float vptx = ffma(om, rcz, vx), vptz = ffma(-om, rcx, vz);
           float vn_prev = 0.0f;
-          if (elast != 0.0f) vn_prev = ffma(-om_old, rcx, vz_old);  // (wave-uniform; with e = 0 the term is exactly 0)
+          if (FL >= 0 ? (FL & 4) != 0 : elast != 0.0f) vn_prev = ffma(-om_old, rcx, vz_old);  // (wave-uniform; with e = 0 the term is exactly 0)
           // (in the plane the slip direction is the sign of vptx: no normalising division, lever arm rcz)
           const float vtn = fabs_(vptx);
           const float icn = rcx * iy_c;

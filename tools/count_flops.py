@@ -25,10 +25,10 @@ INSTANCES = {
     "hopper": "4,false,true,4,2,1,0,0,0,true,false,2,true,true",
     "cartpole": "4,true,true,4,2,1,0,0,0,false,false,2,true",
     # the planar restatement (mbd_planar.h: rollout_planar_kernel<LPS, MAXCOL, D0, D1>) the planar models actually run
-    "hopper_planar": "planar:4,2,1,0",
-    "halfcheetah_planar": "planar:8,2,1,-3",
-    "walker2d_planar": "planar:8,2,1,-3",
-    "cartpole_planar": "planar:4,0,1,0",
+    "hopper_planar": "planar:4,2,1,0,0",
+    "halfcheetah_planar": "planar:8,2,1,-3,1",
+    "walker2d_planar": "planar:8,2,1,-3,0",
+    "cartpole_planar": "planar:4,0,1,0,2",
 }
 
 
