@@ -90,6 +90,11 @@ def count(targs):
     nops = [int(x.split()[1]) for x in loop_text if x.strip().startswith("s_nop")]
     slots = len(best) + sum(v for k, v in c.items() if k.startswith("v_cmp")) + sum(nops) + sum(
         v for k, v in c.items() if k.startswith(("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_")))
+    unroll = 4 if kern == "rollout_planar_kernel" else 2  # (substeps per iteration of the substep loop)
+    if unroll > 1:
+        c = collections.Counter({k: v / unroll for k, v in c.items()})
+        flops, slots, nops = flops / unroll, slots / unroll, nops
+        best = best[:len(best) // unroll]
     res = {"template_args": targs, "instructions_per_substep": len(best), "issue_slots_estimate": slots,
            "valu_per_substep": sum(v for k, v in c.items() if k.startswith("v_")),
            "lds_instr_per_substep": sum(v for k, v in c.items() if k.startswith("ds_")),
