@@ -2,4 +2,5 @@
 cd "$GRAFT_REPO_ROOT" || exit 1
 mkdir -p gpurun_out
 timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3
-tools/gpu_ab2.sh notests metric hopper512 halfcheetah1024 humanoidtrack2048demo humanoidrun4096
+python tools/probes/rollout_timeline.py 2>/dev/null | grep prologue
+tools/gpu_ab2.sh notests metric humanoidtrack2048demo humanoidrun4096
