@@ -179,11 +179,12 @@ def _one_step(gpu, orc, name, N, H, Nd, temp, impl, demo, i=None):
 
 
 @pytest.mark.parametrize("name,H,demo", [("car2d", 7, False), ("car2d", 50, True), ("hopper", 11, False)])
-@pytest.mark.parametrize("N", [1, 3, 63, 64, 65, 1000, 1024, 1025, 2500, 4096, 5003, 20011, 40001])
+@pytest.mark.parametrize("N", [1, 3, 63, 64, 65, 1000, 1024, 1025, 2500, 4096, 5003, 12288, 12289, 20011, 40001])
 def test_score_update_ragged_sizes(gpu, orc, name, H, demo, N):
-    """mbd_plan_score_update on its own, at candidate counts around every boundary of its kernels (one 1024-thread
-    workgroup with logp0 in LDS up to 36 864 candidates and in a global scratch beyond; 16-output x 64-group tiles
-    below 4096 candidates, the row-major two-kernel weighted mean from there): resident Y0s from the sampler,
+    """mbd_plan_score_update on its own, at candidate counts around every boundary of its kernels (score + weighted
+    mean in one launch of 16-output x 64-group tiles while the weights fit 48 KB of LDS — 12 288 candidates; beyond,
+    one 1024-thread score workgroup with logp0 in LDS up to 36 864 candidates and in a global scratch above, and the
+    row-major two-kernel weighted mean): resident candidates from the sampler,
     SYNTHETIC rewards (ties, outliers) and demo log-densities, against the oracle bit for bit — weights, Ybar_{i-1},
     mean reward."""
     import torch
