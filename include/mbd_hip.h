@@ -307,7 +307,10 @@ int mbd_plan_run(mbd_plan* plan, const uint32_t key[2], float* mu_0ts_out, float
 /* rew_final = rollout_us(state_init, Y).mean() for one plan Y [H][Nu] HOST (mbd_planner.py:179-180) */
 int mbd_plan_eval(mbd_plan* plan, const float* Y, float* rew_final_out);
 
-/* device buffers the plan owns (for inspection / parity tests): Y0s [shard][H][Nu], rewss [shard][H] */
+/* what the last step worked on, copied to HOST buffers (inspection / parity tests; synchronises the device): the
+ * candidates Y0s [Nsample][H][Nu] (plans that keep normals instead form them here, from the normals, sigma_i and the
+ * Ybar_i of the last step — between phase 1 and phase 2 the caller's d_Ybar_i must still be unchanged), the shard's
+ * rewss [shard_count][H], the softmax weights [Nsample].  Any pointer may be NULL. */
 int mbd_plan_peek(mbd_plan* plan, float* Y0s_out, float* rewss_out, float* weights_out);
 /* timing of the dominant (rollout) kernel measured with hipEvents on the launch stream:
  * average milliseconds per launch since the last reset; count = launches. reset != 0 clears. */
