@@ -76,3 +76,18 @@ def test_canonical_sum_is_strided_then_butterfly(orc):
         a = np.array([np.float32(a[j] + a[j ^ off]) for j in range(64)], np.float32)
         off >>= 1
     assert orc.lib.orc_sp_sum(x, 1000) == a[0]
+
+
+def test_car2d_collision_threshold_is_the_sqrt_comparison():
+    """csrc/mbd_kernels.h (car2d_rollout_kernel) tests `dx*dx + dy*dy < T` where car2d.py:84 and the checker compare
+    `sqrt(dx*dx + dy*dy) < 0.3f`: T = 0x3db851ec is the smallest float32 whose correctly rounded square root is >= 0.3f,
+    and the correctly rounded square root is monotonic — checked here on every float32 in [0.0899, 0.0901]."""
+    c = np.float32(0.3)
+    lo, hi = np.float32(0.0899), np.float32(0.0901)
+    bits = np.arange(lo.view(np.uint32), hi.view(np.uint32) + 1, dtype=np.uint32)
+    xs = bits.view(np.float32)
+    s = np.sqrt(xs)  # float32: IEEE, correctly rounded
+    T = np.uint32(0x3DB851EC).view(np.float32)
+    assert float(T) == 0.09000000357627869
+    assert np.array_equal(s < c, xs < T)
+    assert np.all(np.diff(s) >= 0)
