@@ -825,3 +825,40 @@ def test_short_exact_sequences(gpu):
     sq = re.findall(r"^(sqrtA|sqrtB|control).*?(\d+) mismatches of (\d+)", out, re.M)
     assert len(sq) == 3 and int(sq[0][1]) == 0 and int(sq[1][1]) == 0 and int(sq[2][1]) > 0, out
     assert all(int(x[2]) == 1910357408 for x in sq), out
+
+
+@pytest.mark.parametrize("name,N,demo", [("humanoidrun", 300, False), ("humanoidtrack", 192, True), ("car2d", 257, False)])
+def test_phase2_kernel_variants_and_shared_device_are_bit_identical(gpu, name, N, demo, monkeypatch):
+    """Phase 2 has three forms that must give the same bits: score + weighted mean in one launch (the default up to
+    12 288 candidates), score_kernel + the tile weighted mean (MBD_NO_FUSED_SCORE=1), score_kernel + the row-major
+    two-kernel weighted mean (MBD_WMEAN_SPLIT=1).  And a plan that shares its device with another live plan (it then
+    generates its normals in front of each rollout instead of beside the previous one) equals the plan run alone."""
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.mbd_planner import Args, Plan
+    env = get_env(name)
+    args = Args(env_name=name, Nsample=N, Hsample=50, Ndiffuse=7, temp_sample=0.1, enable_demo=demo,
+                disable_recommended_params=True, not_render=True)
+    st = env.reset(gpu.prng_key(4))
+    key = gpu.prng_key(9)
+
+    def run(**envs):
+        for k, v in envs.items():
+            monkeypatch.setenv(k, v)
+        p = Plan(env, args)
+        p.set_state0(st)
+        out = p.run(key)[:3]
+        w = p.peek()[2]
+        p.close()
+        for k in envs:
+            monkeypatch.delenv(k)
+        return out, w
+
+    (mu0, rm0, rf0), w0 = run()
+    for envs in (dict(MBD_NO_FUSED_SCORE="1"), dict(MBD_WMEAN_SPLIT="1")):
+        (mu, rm, rf), w = run(**envs)
+        assert np.array_equal(mu, mu0) and np.array_equal(rm, rm0) and rf == rf0 and np.array_equal(w, w0), envs
+    other = Plan(env, args)  # a second live plan on the device
+    other.set_state0(st)
+    (mu, rm, rf), w = run()
+    other.close()
+    assert np.array_equal(mu, mu0) and np.array_equal(rm, rm0) and rf == rf0 and np.array_equal(w, w0)

@@ -118,7 +118,7 @@ def main():
         print(env, json.dumps(res))
         if "--hist" in sys.argv:
             for k, v in c.most_common():
-                print(f"{v:5d} {k}")
+                print(f"{v:7.2f} {k}")
     if "--write" in sys.argv:
         with open(os.path.join(ROOT, "profiles", f"{tag}_static_flops.json"), "w") as f:
             json.dump(out, f, indent=1)
