@@ -68,7 +68,8 @@ __device__ __forceinline__ void pl_qupdate(float& w, float& y, float dth) {
 // bit 1: some slide dof has a finite range (slide_limits), bit 2: elasticity != 0 — or -1: read them at run time.  As
 // run-time flags each is a taken forward branch per substep for the models that lack the feature (every built-in one
 // lacks two or three), and a lone wavefront pays for a taken branch with a refill of its instruction buffer.
-template <int LPS, int MAXCOL, int D0 = 0, int D1 = 0, int FL = -1>
+// RK: the model's reward kind as a compile-time constant (-1: run time), like rollout_kernel's.
+template <int LPS, int MAXCOL, int D0 = 0, int D1 = 0, int FL = -1, int RK = -1>
 __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   constexpr bool DPP = D0 != 0;
   constexpr int NSLOT = DPP ? (D1 != 0 ? 2 : 1) : kMaxChildren;
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   const float two_inv_dt = 2.0f * inv_dt;
   const float coll_scale = M->collide_scale, mu = M->friction, elast = M->elasticity;
   const float gx = link_ok ? M->gravity[0] : 0.0f, gz = link_ok ? M->gravity[2] : 0.0f;
-  const int rkind = M->reward_kind;
+  const int rkind = RK >= 0 ? RK : M->reward_kind;
   const float rp0 = M->reward_params[0], rp1 = M->reward_params[1];
   const float dt_ctrl = M->dt * (float)nfr;
 
@@ -494,6 +495,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       }
     };
     {
+      phase_pad<mbd_pad_planar(LPS, MAXCOL, D0, D1, FL, RK)>();  // (code placement: tools/tune_phase.py)
       int fr = 0;
       for (; fr + 3 < nfr; fr += 4) { substep(); substep(); substep(); substep(); }
       for (; fr < nfr; ++fr) substep();

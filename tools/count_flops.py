@@ -16,19 +16,19 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # env -> template arguments of the instantiation launch_rollout() picks for it (csrc/mbd_capi.hip)
 INSTANCES = {
-    "humanoidrun": "16,true,false,3,1,1,-4,-6,0,false,true",
-    "humanoidtrack": "16,true,false,3,1,1,-4,-6,0,false,true",
-    "humanoidstandup": "16,true,false,3,5,1,-4,-6,0,false,true",
+    "humanoidrun": "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,0",
+    "humanoidtrack": "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,3",
+    "humanoidstandup": "16,true,false,3,5,1,-4,-6,0,false,true,3,false,false,4",
     "ant": "16,true,false,4,2,1,-2,-4,-6,false,false",
     "halfcheetah": "8,true,true,4,2,1,-3,0,0,false,false,2,true",
     "walker2d": "8,false,true,4,2,1,-3,0,0,true,false,2,true,true",
     "hopper": "4,false,true,4,2,1,0,0,0,true,false,2,true,true",
     "cartpole": "4,true,true,4,2,1,0,0,0,false,false,2,true",
     # the planar restatement (mbd_planar.h: rollout_planar_kernel<LPS, MAXCOL, D0, D1>) the planar models actually run
-    "hopper_planar": "planar:4,2,1,0,0",
-    "halfcheetah_planar": "planar:8,2,1,-3,1",
-    "walker2d_planar": "planar:8,2,1,-3,0",
-    "cartpole_planar": "planar:4,0,1,0,2",
+    "hopper_planar": "planar:4,2,1,0,0,1",
+    "halfcheetah_planar": "planar:8,2,1,-3,1,2",
+    "walker2d_planar": "planar:8,2,1,-3,0,1",
+    "cartpole_planar": "planar:4,0,1,0,2,5",
 }
 
 
@@ -70,7 +70,11 @@ def count(targs):
     # the substep loop touches no global memory (actions are fetched per CONTROL step, rewards stored per control step):
     # the longest backward-branch region without a global / flat / scratch access
     nomem = [t for t in loops if not any(x.startswith(("global_", "flat_", "scratch_", "buffer_")) for x in t[2])]
-    bt = max(nomem or inner, key=lambda t: len(t[2]))
+    # ... that does not itself contain another such region of comparable size (the remainder loop of the unrolled
+    # substeps can close a region around the unrolled loop)
+    cands = sorted(nomem or inner, key=lambda t: -len(t[2]))
+    bt = next(t for t in cands
+              if not any(u is not t and u[0] >= t[0] and u[1] <= t[1] and len(u[2]) >= 0.45 * len(t[2]) for u in cands))
     best, loop_text = bt[2], body[bt[0]:bt[1] + 1]
     c = collections.Counter(best)
     flops = 0
