@@ -18,7 +18,7 @@ import sys
 import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
-LOOKBACK = 96
+STRADDLE, PROMOTE = 0.8, 0.125  # issue slots: a straddling 8-byte instruction; 4 more bytes of code (1 slot per 32)
 TARGET_FUNCS = ("3mbd14rollout_kernel", "3mbd21rollout_planar_kernel")  # (mangled: not car2d_rollout_kernel)
 
 
@@ -84,33 +84,63 @@ def fix(asm_text):
                     raise RuntimeError(f"{name}: instruction {i}: '{lines[k].strip()}' in the assembly, '{sz[i][1]}' in the object")
             sz = [x[0] for x in sz[:len(idx)]]
             promotable = [bool(re.match(r"^v_\w+_e32\b", lines[k].strip())) and sz[i] == 4 for i, k in enumerate(idx)]
-            before = 0
-            off, i, promoted, left = 0, 0, 0, 0
-            offs = [0] * len(idx)
-            # straddles before
-            o = 0
+            before, o = 0, 0
             for s_ in sz:
                 before += s_ == 8 and o % 32 == 28
                 o += s_
-            while i < len(idx):
-                offs[i] = off
-                if sz[i] == 8 and off % 32 == 28:
-                    # the nearest promotable instruction in front, in this fetch piece or up to LOOKBACK bytes before it
-                    # (everything behind it moves by 4 bytes: the scan resumes there and repairs what that moves into
-                    # a straddle — each repair uses up a promotable instruction, so it ends)
-                    j = i - 1
-                    while j >= 0 and offs[j] >= off - 28 - LOOKBACK and not promotable[j]:
-                        j -= 1
-                    if j >= 0 and offs[j] >= off - 28 - LOOKBACK and promotable[j]:
-                        k = idx[j]
-                        lines[k] = re.sub(r"^(\s*v_\w+)_e32\b", r"\1_e64", lines[k], count=1)
-                        sz[j], promotable[j] = 8, False
-                        promoted += 1
-                        off, i = offs[j], j  # rescan from the promoted instruction
+            # how often an instruction runs: 30^(loop depth), loops = regions closed by a backward branch to a label
+            lab, depth = {}, [0] * len(idx)
+            pos = {k: i for i, k in enumerate(idx)}
+            nxt = len(idx)
+            first_instr_at = [0] * (b - a + 1)
+            for k in range(b, a - 1, -1):  # line -> index of the first instruction at or after it
+                if k in pos:
+                    nxt = pos[k]
+                first_instr_at[k - a] = nxt
+            for k in range(a, b):
+                m = re.match(r"^(\.LBB\d+_\d+):", lines[k])
+                if m:
+                    lab[m.group(1)] = first_instr_at[k - a]
+            for i, k in enumerate(idx):
+                m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", lines[k])
+                if m and m.group(1) in lab and lab[m.group(1)] <= i:
+                    for t in range(lab[m.group(1)], i + 1):
+                        depth[t] += 1
+            weight = [30.0 ** min(d, 3) for d in depth]
+            # Dynamic programme over (instruction, offset mod 32): which promotable instructions to re-encode so that
+            # the weighted cost — STRADDLE per straddling 8-byte instruction, PROMOTE per 4 bytes of added code — is least
+            INF = float("inf")
+            n = len(idx)
+            cost = [[INF] * 8 for _ in range(n + 1)]
+            back = [[None] * 8 for _ in range(n + 1)]
+            cost[0][0] = 0.0
+            for i in range(n):
+                w = weight[i]
+                for ph in range(8):
+                    c = cost[i][ph]
+                    if c == INF:
                         continue
-                    left += 1
-                off += sz[i]
-                i += 1
+                    for prom in ((False, True) if promotable[i] else (False,)):
+                        size = 8 if prom else sz[i]
+                        cc = c + (PROMOTE * w if prom else 0.0) + (STRADDLE * w if (size == 8 and ph == 7) else 0.0)
+                        np_ = (ph + size // 4) % 8
+                        if cc < cost[i + 1][np_]:
+                            cost[i + 1][np_] = cc
+                            back[i + 1][np_] = (ph, prom)
+            ph = min(range(8), key=lambda q: cost[n][q])
+            promoted = 0
+            for i in range(n, 0, -1):
+                pph, prom = back[i][ph]
+                if prom:
+                    k = idx[i - 1]
+                    lines[k] = re.sub(r"^(\s*v_\w+)_e32\b", r"\1_e64", lines[k], count=1)
+                    sz[i - 1] = 8
+                    promoted += 1
+                ph = pph
+            left, o = 0, 0
+            for s_ in sz:
+                left += s_ == 8 and o % 32 == 28
+                o += s_
             stats[name] = dict(instructions=len(idx), straddles_before=before, promoted=promoted, left=left)
         fixed = "\n".join(lines)
         # the promoted encodings must assemble to exactly the predicted sizes, and no straddle may remain unaccounted for
