@@ -520,7 +520,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       cart_vs = ffma(vcx, sx[0], vcz * sz[0]);     // own slide-0 velocity: used on link 0's lane
       cart_cos = shfl(cs, lane_of(1));
     }
-    if (root_lane) {
+    {  // (every lane evaluates it, the root lane's is kept; the store is the expected side: rollout_kernel's note)
       float rew;
       if (rkind == MBD_REW_HOPPER) {
         rew = o1x - fclip(fabs_(o1z - rp0), -1.0f, 1.0f) * rp1;
@@ -530,7 +530,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         rew = cart_cos - fabs_(cart_vs);
       }
       rew_sum = rew_sum + rew;
-      if (b_ok && P.rewss) P.rewss[(size_t)b * H + t] = rew;
+      if (__builtin_expect(root_lane && b_ok && P.rewss != nullptr, 1)) P.rewss[(size_t)b * H + t] = rew;
     }
     u_rot = un_rot; u_sl0 = un_sl0; u_sl1 = un_sl1;
     y_rot = yn_rot; y_sl0 = yn_sl0; y_sl1 = yn_sl1;
