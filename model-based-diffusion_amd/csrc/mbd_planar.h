@@ -69,8 +69,13 @@ __device__ __forceinline__ void pl_qupdate(float& w, float& y, float dth) {
 // run-time flags each is a taken forward branch per substep for the models that lack the feature (every built-in one
 // lacks two or three), and a lone wavefront pays for a taken branch with a refill of its instruction buffer.
 // RK: the model's reward kind as a compile-time constant (-1: run time), like rollout_kernel's.
-template <int LPS, int MAXCOL, int D0 = 0, int D1 = 0, int FL = -1, int RK = -1>
+// NFR: the model's n_frames (even) as a compile-time constant, or 0: read at run time.  The substep loop then runs
+// twice over NFR / 2 substeps in line instead of NFR / 4 times over four plus a remainder loop: every iteration saved is
+// a taken branch (hopper, n_frames = 20: 7 -> 2 per control step, +2.7 % at N = 512; the in-line body stays under
+// ~30 KB — the humanoid's seven substeps in line, 39 KB, lost 1.9 %).
+template <int LPS, int MAXCOL, int D0 = 0, int D1 = 0, int FL = -1, int RK = -1, int NFR = 0>
 __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
+  static_assert(NFR % 2 == 0, "NFR: two iterations of NFR / 2");
   constexpr bool DPP = D0 != 0;
   constexpr int NSLOT = DPP ? (D1 != 0 ? 2 : 1) : kMaxChildren;
   if ((int)blockIdx.x >= P.roll_blocks) {  // the next step's normals, on CUs the rollout leaves idle (mbd_kernels.h)
@@ -92,7 +97,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   const int b_raw = wave_id * SPW + lane / LPS;
   const bool b_ok = b_raw < P.B;
   const int b = b_ok ? b_raw : P.B - 1;
-  const int H = P.H, Nu = M->n_act, nfr = M->n_frames;
+  const int H = P.H, Nu = M->n_act, nfr = NFR > 0 ? NFR : M->n_frames;
 
   // ---- per-lane model constants (padding lanes: everything that scales a contribution is zero) ------------
   const int parent = M->parent[l];
@@ -495,10 +500,14 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       }
     };
     {
-      phase_pad<mbd_pad_planar(LPS, MAXCOL, D0, D1, FL, RK)>();  // (code placement: tools/tune_phase.py)
+      phase_pad<mbd_pad_planar(LPS, MAXCOL, D0, D1, FL, RK, NFR)>();  // (code placement: tools/tune_phase.py)
       int fr = 0;
-      for (; fr + 3 < nfr; fr += 4) { substep(); substep(); substep(); substep(); }
-      for (; fr < nfr; ++fr) substep();
+      if constexpr (NFR > 0) {  // two iterations of NFR / 2 substeps in line
+        for (int it = 0; it < 2; ++it) repeat_n<NFR / 2>(substep);
+      } else {
+        for (; fr + 3 < nfr; fr += 4) { substep(); substep(); substep(); substep(); }
+        for (; fr < nfr; ++fr) substep();
+      }
     }  // substeps
 
     // ---- reward ------------------------------------------------------------------------------------------------

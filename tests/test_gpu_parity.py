@@ -104,6 +104,22 @@ def test_rollout_bitexact_shuffle_fallback(gpu, orc, name, B, H, sigma, monkeypa
     _rollout_bitexact(gpu, orc, name, B, H, sigma)
 
 
+@pytest.mark.parametrize("name,B,H,sigma", [("humanoidrun", 24, 20, 0.6), ("humanoidtrack", 16, 20, 0.4),
+                                            ("humanoidstandup", 12, 20, 0.5), ("hopper", 48, 50, 0.5),
+                                            ("halfcheetah", 24, 50, 0.5), ("walker2d", 24, 30, 0.5),
+                                            ("cartpole", 64, 50, 0.8)])
+def test_rollout_bitexact_general_instantiations(gpu, orc, name, B, H, sigma, monkeypatch):
+    """The built-in models run instantiations with their switches, reward kind and n_frames as compile-time constants;
+    a model that differs in any of them (another MJCF, another n_frames) runs the general instantiation of the same
+    kernel.  Forced here for the built-in models (switches read per launch) and held to the same bar."""
+    for k in ("MBD_NO_PLANAR_FLAGS", "MBD_NO_REWARD_CONST", "MBD_NO_NFR_CONST"):
+        monkeypatch.setenv(k, "1")
+    _rollout_bitexact(gpu, orc, name, B, H, sigma)
+    monkeypatch.delenv("MBD_NO_PLANAR_FLAGS")  # (n_frames at run time under the compile-time switches)
+    monkeypatch.delenv("MBD_NO_REWARD_CONST")
+    _rollout_bitexact(gpu, orc, name, B, H, sigma)
+
+
 def _rollout_bitexact(gpu, orc, name, B, H, sigma):
     from mbd_hip.envs import get_env
     env = get_env(name)

@@ -25,10 +25,11 @@ INSTANCES = {
     "hopper": "4,false,true,4,2,1,0,0,0,true,false,2,true,true",
     "cartpole": "4,true,true,4,2,1,0,0,0,false,false,2,true",
     # the planar restatement (mbd_planar.h: rollout_planar_kernel<LPS, MAXCOL, D0, D1>) the planar models actually run
-    "hopper_planar": "planar:4,2,1,0,0,1",
+    # (the last argument: n_frames as a compile-time constant — the loop runs twice over n_frames / 2 substeps in line)
+    "hopper_planar": "planar:4,2,1,0,0,1,20",
     "halfcheetah_planar": "planar:8,2,1,-3,1,2",
-    "walker2d_planar": "planar:8,2,1,-3,0,1",
-    "cartpole_planar": "planar:4,0,1,0,2,5",
+    "walker2d_planar": "planar:8,2,1,-3,0,1,20",
+    "cartpole_planar": "planar:4,0,1,0,2,5,4",
 }
 
 
@@ -95,6 +96,8 @@ def count(targs):
     slots = len(best) + sum(v for k, v in c.items() if k.startswith("v_cmp")) + sum(nops) + sum(
         v for k, v in c.items() if k.startswith(("v_rcp_", "v_rsq_", "v_sqrt_", "v_exp_", "v_log_")))
     unroll = 4 if kern == "rollout_planar_kernel" else 2  # (substeps per iteration of the substep loop)
+    if kern == "rollout_planar_kernel" and len(targs.split(",")) >= 7 and int(targs.split(",")[6]) > 0:
+        unroll = int(targs.split(",")[6]) // 2
     if unroll > 1:
         c = collections.Counter({k: v / unroll for k, v in c.items()})
         flops, slots, nops = flops / unroll, slots / unroll, nops

@@ -27,10 +27,10 @@ TARGETS = [
     ("3d", "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,3", (1, 3)),    # humanoidtrack
     ("3d", "16,true,false,3,5,1,-4,-6,0,false,true,3,false,false,4", (5, 4)),    # humanoidstandup
     ("3d", "16,true,false,3,1,1,-4,-6,0,false,true", (1, -1)),                    # humanoid-shaped, other rewards
-    ("planar", "4,2,1,0,0,1", (4, 2, 1, 0, 0, 1)),      # hopper
-    ("planar", "8,2,1,-3,0,1", (8, 2, 1, -3, 0, 1)),    # walker2d
-    ("planar", "8,2,1,-3,1,2", (8, 2, 1, -3, 1, 2)),    # halfcheetah
-    ("planar", "4,0,1,0,2,5", (4, 0, 1, 0, 2, 5)),      # cartpole
+    ("planar", "4,2,1,0,0,1,20", (4, 2, 1, 0, 0, 1, 20)),      # hopper
+    ("planar", "8,2,1,-3,0,1,20", (8, 2, 1, -3, 0, 1, 20)),    # walker2d
+    ("planar", "8,2,1,-3,1,2", (8, 2, 1, -3, 1, 2, 0)),        # halfcheetah
+    ("planar", "4,0,1,0,2,5,4", (4, 0, 1, 0, 2, 5, 4)),        # cartpole
 ]
 
 
@@ -126,9 +126,9 @@ def _write(path, res, verbose):
         for (mc, rk), r in rows3:
             f.write(f"(maxcol == {mc} && rk == {rk}) ? {r['pad']} /* {r['now']} -> {r['straddles'][r['shift']]} */\n       : ")
         f.write("0;\n}\n")
-        f.write("constexpr int mbd_pad_planar(int lps, int maxcol, int d0, int d1, int fl, int rk) {\n  return ")
-        for (lps, mc, d0, d1, fl, rk), r in rowsp:
-            f.write(f"(lps == {lps} && maxcol == {mc} && d0 == {d0} && d1 == {d1} && fl == {fl} && rk == {rk}) ? {r['pad']} "
+        f.write("constexpr int mbd_pad_planar(int lps, int maxcol, int d0, int d1, int fl, int rk, int nfr) {\n  return ")
+        for (lps, mc, d0, d1, fl, rk, nfr), r in rowsp:
+            f.write(f"(lps == {lps} && maxcol == {mc} && d0 == {d0} && d1 == {d1} && fl == {fl} && rk == {rk} && nfr == {nfr}) ? {r['pad']} "
                     f"/* {r['now']} -> {r['straddles'][r['shift']]} */\n       : ")
         f.write("0;\n}\n")
     os.replace(path + ".tmp", path)
