@@ -16,9 +16,9 @@ import tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 # env -> template arguments of the instantiation launch_rollout() picks for it (csrc/mbd_capi.hip)
 INSTANCES = {
-    "humanoidrun": "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,0",
-    "humanoidtrack": "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,3",
-    "humanoidstandup": "16,true,false,3,5,1,-4,-6,0,false,true,3,false,false,4",
+    "humanoidrun": "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,0,7",
+    "humanoidtrack": "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,3,5",
+    "humanoidstandup": "16,true,false,3,5,1,-4,-6,0,false,true,3,false,false,4,7",
     "ant": "16,true,false,4,2,1,-2,-4,-6,false,false",
     "halfcheetah": "8,true,true,4,2,1,-3,0,0,false,false,2,true",
     "walker2d": "8,false,true,4,2,1,-3,0,0,true,false,2,true,true",
@@ -98,6 +98,8 @@ def count(targs):
     unroll = 4 if kern == "rollout_planar_kernel" else 2  # (substeps per iteration of the substep loop)
     if kern == "rollout_planar_kernel" and len(targs.split(",")) >= 7 and int(targs.split(",")[6]) > 0:
         unroll = int(targs.split(",")[6]) // 2
+    if kern == "rollout_kernel" and len(targs.split(",")) >= 16 and int(targs.split(",")[15]) > 0:
+        unroll = int(targs.split(",")[15]) // 2
     if unroll > 1:
         c = collections.Counter({k: v / unroll for k, v in c.items()})
         flops, slots, nops = flops / unroll, slots / unroll, nops

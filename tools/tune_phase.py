@@ -23,9 +23,9 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-fn
          "-fhip-fp32-correctly-rounded-divide-sqrt", "-DMBD_PHASE_TUNING", "-S", "--cuda-device-only"]
 # (kind, template arguments, key of the generated table)
 TARGETS = [
-    ("3d", "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,0", (1, 0)),    # humanoidrun
-    ("3d", "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,3", (1, 3)),    # humanoidtrack
-    ("3d", "16,true,false,3,5,1,-4,-6,0,false,true,3,false,false,4", (5, 4)),    # humanoidstandup
+    ("3d", "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,0,7", (1, 0)),  # humanoidrun
+    ("3d", "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,3,5", (1, 3)),  # humanoidtrack
+    ("3d", "16,true,false,3,5,1,-4,-6,0,false,true,3,false,false,4,7", (5, 4)),  # humanoidstandup
     ("3d", "16,true,false,3,1,1,-4,-6,0,false,true", (1, -1)),                    # humanoid-shaped, other rewards
     ("planar", "4,2,1,0,0,1,20", (4, 2, 1, 0, 0, 1, 20)),      # hopper
     ("planar", "8,2,1,-3,0,1,20", (8, 2, 1, -3, 0, 1, 20)),    # walker2d
