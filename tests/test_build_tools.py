@@ -52,3 +52,22 @@ def test_fix_straddles_changes_encodings_only(tmp_path):
     (tmp_path / "f.s").write_text(fixed)
     subprocess.run(["/opt/rocm/lib/llvm/bin/clang", "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c",
                     str(tmp_path / "f.s"), "-o", str(out)], check=True, capture_output=True)
+
+
+@pytest.mark.skipif(not os.path.exists("/opt/rocm/bin/hipcc"), reason="no hipcc")
+def test_measurement_tools_find_the_substep_loop_of_a_product_kernel():
+    """tools/count_flops.py (the `issued` side of the bench's valu block, profiles/r02_static_flops.json) and
+    tools/tune_phase.py (code placement) both locate the substep loop in the emitted ISA of a real instantiation — the
+    cartpole's planar kernel, the smallest one: same loop, no scratch, no memory access inside it."""
+    import count_flops
+    import tune_phase
+    targs = count_flops.INSTANCES["cartpole_planar"]
+    res, hist = count_flops.count(targs)
+    assert res["scratch_bytes"] == 0 and 200 < res["instructions_per_substep"] < 400
+    assert res["fp32_flops_per_lane_substep"] > res["valu_per_substep"]  # (packed and fused ops count 2 and 4)
+    assert not any(k.startswith(("global_", "flat_", "scratch_", "buffer_")) for k in hist)
+    kind, t, _ = next(x for x in tune_phase.TARGETS if x[0] == "planar" and "planar:" + x[1] == targs)
+    ph = tune_phase.analyse(kind, t)
+    unroll = int(t.split(",")[6]) // 2
+    assert abs(ph["instructions"] - unroll * res["instructions_per_substep"]) <= unroll + 8  # (+ the loop's own bookkeeping)
+    assert set(ph["straddles"]) == set(range(0, 32, 4)) and ph["straddles"][ph["shift"]] == min(ph["straddles"].values())
