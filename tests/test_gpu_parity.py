@@ -120,6 +120,27 @@ def test_rollout_bitexact_general_instantiations(gpu, orc, name, B, H, sigma, mo
     _rollout_bitexact(gpu, orc, name, B, H, sigma)
 
 
+@pytest.mark.parametrize("name,nf,B,H", [("humanoidrun", 1, 12, 20), ("humanoidrun", 4, 12, 12), ("humanoidrun", 9, 8, 8),
+                                         ("humanoidstandup", 3, 8, 10), ("hopper", 7, 32, 20), ("hopper", 21, 16, 10),
+                                         ("halfcheetah", 5, 16, 20), ("cartpole", 3, 32, 20), ("walker2d", 1, 16, 20)])
+def test_rollout_bitexact_other_n_frames(gpu, orc, name, nf, B, H):
+    """n_frames is a compile-time constant of the instantiations the built-in models run (NFR); a model with another
+    value — odd, 1, larger than any built-in — takes the run-time loops (pairs / fours plus a remainder)."""
+    from conftest import load_model
+    from mbd_hip.envs.base import RigidBodyEnv
+    m = load_model(name)
+    m.fields["n_frames"] = nf
+    env = RigidBodyEnv(name, model=m)
+    st = env.reset(gpu.prng_key(5))
+    rng = np.random.default_rng(nf * 100 + B)
+    us = np.clip(rng.normal(size=(B, H, env.action_size)) * 0.5, -1.3, 1.3).astype(np.float32)
+    want = env.xref is not None
+    out = env.rollout(st, us, want_xpos=want)
+    ref = _oenv(orc, env).rollout(np.asarray(st.pipeline_state, np.float32), us, want_xpos=want)
+    got = (out[0] if want else out).cpu().numpy()
+    assert np.isfinite(got).all() and np.array_equal(got, ref[0] if want else ref), f"{name} n_frames={nf}"
+
+
 def _rollout_bitexact(gpu, orc, name, B, H, sigma):
     from mbd_hip.envs import get_env
     env = get_env(name)
