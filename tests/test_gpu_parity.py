@@ -141,6 +141,31 @@ def test_rollout_bitexact_other_n_frames(gpu, orc, name, nf, B, H):
     assert np.isfinite(got).all() and np.array_equal(got, ref[0] if want else ref), f"{name} n_frames={nf}"
 
 
+@pytest.mark.parametrize("no_dpp", [False, True])
+def test_custom_mjcf_model_on_the_general_kernels(gpu, orc, no_dpp, monkeypatch):
+    """A model only a custom MJCF file produces (tests/custom_models.py: full inertia tensors, 1/2/3-dof hinges with
+    springs and dampers, a slide + hinge joint, four children on the root, two colliders on one link) through
+    mjcf.load -> mbd_env_create_model -> the general 3-D instantiation, rollouts and one planning step, bit for bit."""
+    from custom_models import CRAB
+    from test_oracle_physics import _compile
+    from mbd_hip.envs.base import RigidBodyEnv
+    if no_dpp:
+        monkeypatch.setenv("MBD_NO_DPP", "1")
+    m = _compile(CRAB, env_name="hopper", n_frames=3, reset_noise=0.02, reward_params=(1.0, 0.5))
+    F = m.fields
+    assert F["iso_inertia"] == 0 and np.abs(F["inv_inertia"][:m.n_links, 3:]).max() > 1.0  # (not even diagonal)
+    assert F["n_slide"].max() == 1 and F["n_rot"].max() == 3 and np.bincount(F["parent"][1:m.n_links]).max() == 4
+    env = RigidBodyEnv("hopper", model=m)
+    st = env.reset(gpu.prng_key(11))
+    rng = np.random.default_rng(4)
+    us = np.clip(rng.normal(size=(37, 25, env.action_size)) * 0.6, -1.3, 1.3).astype(np.float32)
+    got = env.rollout(st, us).cpu().numpy()
+    ref = _oenv(orc, env).rollout(np.asarray(st.pipeline_state, np.float32), us)
+    assert np.isfinite(got).all() and np.ptp(got) > 1e-3
+    assert np.array_equal(got, ref), f"max |d| = {np.abs(got - ref).max()}"
+    _one_step(gpu, orc, "hopper", 96, 12, 20, 0.1, 1, False, i=12, env=env)
+
+
 def _rollout_bitexact(gpu, orc, name, B, H, sigma):
     from mbd_hip.envs import get_env
     env = get_env(name)
@@ -179,12 +204,12 @@ def test_env_step_matches_oracle(gpu, orc, name):
         assert np.float32(st.reward) == np.float32(r_ref)
 
 
-def _one_step(gpu, orc, name, N, H, Nd, temp, impl, demo, i=None):
+def _one_step(gpu, orc, name, N, H, Nd, temp, impl, demo, i=None, env=None):
     from mbd_hip.envs import get_env
     from mbd_hip.planners.mbd_planner import Args, Plan
     from oracle import planner as op
     import torch
-    env = get_env(name)
+    env = get_env(name) if env is None else env
     args = Args(env_name=name, Nsample=N, Hsample=H, Ndiffuse=Nd, temp_sample=temp, enable_demo=demo,
                 disable_recommended_params=True, not_render=True)
     key = gpu.prng_key(1)
