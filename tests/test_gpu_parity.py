@@ -166,6 +166,28 @@ def test_custom_mjcf_model_on_the_general_kernels(gpu, orc, no_dpp, monkeypatch)
     _one_step(gpu, orc, "hopper", 96, 12, 20, 0.1, 1, False, i=12, env=env)
 
 
+@pytest.mark.parametrize("planar", [None, False])
+def test_custom_planar_model_sixteen_lane_groups(gpu, orc, planar):
+    """tests/custom_models.py TRIPOD: a planar model of ten links — a 16-lane candidate group, which no built-in planar
+    model needs — with joint springs, a limited root slide and restitution all at once (the planar kernel's run-time
+    switches), as the planar restatement (MBD_FLAG_PLANAR) and, compiled with planar=False, through the 3-D
+    arithmetic of the general axisymmetric 16-lane instantiation.  Each against the checker's matching arithmetic."""
+    from custom_models import TRIPOD
+    from test_oracle_physics import _compile
+    from mbd_hip.envs.base import RigidBodyEnv
+    m = _compile(TRIPOD, env_name="halfcheetah", n_frames=6, reset_noise=0.05, reward_params=(1.0, 0.1), planar=planar)
+    assert m.n_links == 10 and bool(m.fields["flags"] & 2) == (planar is None)
+    env = RigidBodyEnv("halfcheetah", model=m)
+    st = env.reset(gpu.prng_key(2))
+    rng = np.random.default_rng(9)
+    us = np.clip(rng.normal(size=(29, 30, env.action_size)) * 0.6, -1.3, 1.3).astype(np.float32)
+    got = env.rollout(st, us).cpu().numpy()
+    ref = _oenv(orc, env).rollout(np.asarray(st.pipeline_state, np.float32), us)
+    assert np.isfinite(got).all() and np.ptp(got) > 1e-3
+    assert np.array_equal(got, ref), f"max |d| = {np.abs(got - ref).max()}"
+    _one_step(gpu, orc, "halfcheetah", 80, 10, 20, 0.4, 1, False, i=10, env=env)
+
+
 def _rollout_bitexact(gpu, orc, name, B, H, sigma):
     from mbd_hip.envs import get_env
     env = get_env(name)
