@@ -888,6 +888,57 @@ def test_general_3d_kernels_on_planar_models(gpu, orc_omp, name, B, no_dpp, monk
     assert np.array_equal(got, ref), f"{name}: max |d| = {np.abs(got - ref).max()}"
 
 
+@pytest.mark.parametrize("no_dpp", [False, True])
+@pytest.mark.parametrize("cls", ["iso", "diag", "full"])
+@pytest.mark.parametrize("name", ["hopper", "walker2d", "tripod", "humanoidrun", "ant"])
+def test_general_3d_kernels_by_inertia_class(gpu, orc, name, cls, no_dpp, monkeypatch):
+    """launch_rollout picks an instantiation by candidate-group width (4 / 8 / 16 lanes), exchange (a DPP family or
+    shuffles) and the CLASS of the model's inverse-inertia tensors: isotropic, axisymmetric, diagonal, full.  The
+    built-in models populate only some of the combinations; here the tensors of built-in trees are replaced (the
+    checker reads the same model), planar models run their 3-D arithmetic, and every combination is held to the bar."""
+    if no_dpp:
+        monkeypatch.setenv("MBD_NO_DPP", "1")
+    from conftest import load_model
+    from mbd_hip.envs.base import RigidBodyEnv
+    from oracle.planner import OracleEnv
+    if name == "tripod":
+        from custom_models import TRIPOD
+        from test_oracle_physics import _compile
+        m = _compile(TRIPOD, env_name="halfcheetah", n_frames=4, reset_noise=0.05, reward_params=(1.0, 0.1), planar=False)
+        ename = "halfcheetah"
+    else:
+        m, ename = load_model(name), name
+        m.fields["n_frames"] = min(int(m.fields["n_frames"]), 5)
+    m.fields["flags"] = int(m.fields["flags"]) & ~2
+    g = np.random.default_rng(len(name) * 7 + len(cls))
+    Iinv = np.array(m.fields["inv_inertia"], np.float32)
+    for l in range(m.n_links):
+        a = float(Iinv[l, :3].mean())
+        if cls == "iso":
+            Iinv[l] = [a, a, a, 0, 0, 0]
+        elif cls == "diag":
+            Iinv[l] = [a * 0.7, a * 1.1, a * 1.6, 0, 0, 0]
+        else:  # a rotated diagonal tensor: symmetric positive definite with all six entries non-zero
+            q = g.normal(size=4); q /= np.linalg.norm(q)
+            w, x, y, z = q
+            R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y)],
+                          [2 * (x * y + w * z), 1 - 2 * (x * x + z * z), 2 * (y * z - w * x)],
+                          [2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)]])
+            T = R @ np.diag([a * 0.7, a * 1.1, a * 1.6]) @ R.T
+            Iinv[l] = [T[0, 0], T[1, 1], T[2, 2], T[0, 1], T[0, 2], T[1, 2]]
+    m.fields["inv_inertia"] = Iinv
+    m.fields["iso_inertia"] = int(cls == "iso")
+    env = RigidBodyEnv(ename, model=m)
+    st = env.reset(gpu.prng_key(6))
+    B, H = 21, 12
+    us = np.clip(g.normal(size=(B, H, env.action_size)) * 0.6, -1.2, 1.2).astype(np.float32)
+    got = env.rollout(st, us).cpu().numpy()
+    oe = OracleEnv(orc, ename, m.to_struct(), init_q=m.init_q)
+    ref = oe.rollout(np.asarray(st.pipeline_state, np.float32), us)
+    assert np.isfinite(got).all()
+    assert np.array_equal(got, ref), f"{name}/{cls}: max |d| = {np.abs(got - ref).max()}"
+
+
 def test_short_exact_sequences(gpu):
     """The value-preserving shortcuts of csrc/mbd_math.h, on the device that runs them: rcp + one Newton
     step is the correctly rounded reciprocal for EVERY float32 in [1e-20, 1e20]; with it ONE residual step gives the
