@@ -7,7 +7,7 @@ import numpy as np, torch
 from mbd_hip import _capi
 from mbd_hip.envs import get_env
 H = 50
-for name, B in (("humanoidrun", 1024), ("humanoidtrack", 2048), ("humanoidstandup", 1024), ("hopper", 512),
+for name, B in (("humanoidrun", 1024), ("humanoidtrack", 2048), ("humanoidstandup", 1024), ("ant", 1024), ("hopper", 512),
                 ("walker2d", 1024), ("cartpole", 1024)):
     env = get_env(name)
     st = env.reset(_capi.prng_key(1))
