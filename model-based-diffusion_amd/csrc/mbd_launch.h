@@ -1,0 +1,47 @@
+// mbd_launch.h — the one launch site of every rollout instantiation (host side; shared by the translation units that
+// hold rollout kernels: mbd_capi.hip and mbd_pk2.hip).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <set>
+#include <utility>
+
+#include "mbd_kernels.h"
+
+namespace mbd {
+
+// One launch site for every instantiation.  lds > 0 reserves dynamic LDS the kernel never touches: more than half
+// of a CU's 160 KB keeps a second workgroup — of this or of a concurrent plan's launch — off the CU, so concurrent
+// plans spread over the chip instead of piling onto the CUs the dispatcher fills first (tools/gpu_concurrent.sh).
+template <typename K>
+inline hipError_t launch_rollout_kernel(K kernel, int device, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                                 const RolloutParams& P) {
+  if (lds > 0) {
+    // > 64 KB of dynamic LDS needs the attribute on EVERY instantiation that is launched that way; all of them share
+    // this function's signature, so the bookkeeping is keyed on (kernel address, device)
+    static std::mutex mu;
+    static std::set<std::pair<const void*, int>> raised;
+    std::lock_guard<std::mutex> g(mu);
+    const auto key = std::make_pair((const void*)kernel, device);
+    if (!raised.count(key)) {
+      hipError_t e = hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+      if (e != hipSuccess) return e;
+      raised.insert(key);
+    }
+  }
+  hipLaunchKernelGGL(kernel, grid, block, lds, stream, P);
+  return hipGetLastError();
+}
+
+
+// the two-candidates-per-lane rollouts of the humanoid family (mbd_pk2.h; their own translation unit, mbd_pk2.hip, built
+// with the scheduler strategy that keeps dependent packed instructions apart).  hipErrorInvalidValue: no such instantiation.
+// wpe: 2 asks for the instantiation whose registers leave room for two wavefronts per SIMD (where there is one).
+hipError_t launch_rollout_pk2(int maxcol, int rk, int nfr, int wpe, int device, dim3 grid, dim3 block, size_t lds,
+                              hipStream_t stream, const RolloutParams& P);
+// (maxcol, rk, nfr) the launcher would run for a model with `max_col` colliders per link, reward kind `rk`, `nfr` frames
+bool pk2_instantiation(int max_col, int rk, int nfr, int out[3]);
+
+}  // namespace mbd

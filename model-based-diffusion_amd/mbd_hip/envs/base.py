@@ -110,9 +110,9 @@ class _EnvBase:
     def _next_done(self, state):
         return np.float32(0.0)
 
-    def rollout(self, state: State, us, want_xpos: bool = False):
+    def rollout(self, state: State, us, want_xpos: bool = False, want_final: bool = False):
         """Batched rollout on the GPU. ``us``: [B,H,Nu] numpy array or CUDA torch tensor.
-        Returns rewss [B,H] (and xpos [B,H,K,3]) as CUDA torch tensors."""
+        Returns rewss [B,H] (and xpos [B,H,K,3]; and the final pipeline states [B, state_size]) as CUDA torch tensors."""
         import torch
         dev = torch.device("cuda", self.device)
         us_t = torch.as_tensor(us, dtype=torch.float32, device=dev).contiguous()
@@ -123,10 +123,13 @@ class _EnvBase:
         xpos = None
         if want_xpos:
             xpos = torch.empty((B, H) + self._xpos_shape(), dtype=torch.float32, device=dev)
+        final = torch.empty((B, s0.numel()), dtype=torch.float32, device=dev) if want_final else None
         stream = torch.cuda.current_stream(dev).cuda_stream
         _capi.check(self._lib.mbd_env_rollout(self._h, s0.data_ptr(), us_t.data_ptr(), B, H, rewss.data_ptr(),
-                                              xpos.data_ptr() if want_xpos else None, None, stream))
-        return (rewss, xpos) if want_xpos else rewss
+                                              xpos.data_ptr() if want_xpos else None,
+                                              final.data_ptr() if want_final else None, stream))
+        out = (rewss,) + ((xpos,) if want_xpos else ()) + ((final,) if want_final else ())
+        return out if len(out) > 1 else rewss
 
     def __del__(self):
         try:

@@ -997,3 +997,45 @@ def test_phase2_kernel_variants_and_shared_device_are_bit_identical(gpu, name, N
     (mu, rm, rf), w = run()
     other.close()
     assert np.array_equal(mu, mu0) and np.array_equal(rm, rm0) and rf == rf0 and np.array_equal(w, w0)
+
+# ---- two candidates per lane (mbd_pk2.h) -----------------------------------------------------------------------------
+@pytest.mark.parametrize("name,B,H,sigma", [("humanoidrun", 96, 50, 0.6), ("humanoidrun", 1, 3, 0.3),
+                                            ("humanoidrun", 37, 20, 0.9), ("humanoidtrack", 64, 50, 0.4),
+                                            ("humanoidtrack", 9, 12, 0.4), ("humanoidstandup", 36, 50, 0.5)])
+def test_pk2_rollout_bitexact(gpu, orc, name, B, H, sigma, monkeypatch):
+    """rollout_pk2_kernel — a lane holds its link for the candidates (2k, 2k+1), all arithmetic as v_pk_*_f32 — forced
+    with MBD_PK2=1 (launches pick it by themselves only above 4096 candidates) and held to the checker bit for bit,
+    odd batch sizes (a half-filled last pair) included."""
+    monkeypatch.setenv("MBD_PK2", "1")
+    _rollout_bitexact(gpu, orc, name, B, H, sigma)
+
+
+@pytest.mark.parametrize("name,B,H", [("humanoidrun", 24, 20), ("humanoidtrack", 16, 20), ("humanoidstandup", 12, 20)])
+def test_pk2_general_instantiations(gpu, orc, name, B, H, monkeypatch):
+    monkeypatch.setenv("MBD_PK2", "1")
+    for k in ("MBD_NO_REWARD_CONST", "MBD_NO_NFR_CONST"):
+        monkeypatch.setenv(k, "1")
+    _rollout_bitexact(gpu, orc, name, B, H, 0.5)
+
+
+@pytest.mark.parametrize("name,B", [("humanoidrun", 8192), ("humanoidtrack", 4100), ("humanoidstandup", 4099)])
+def test_pk2_is_bit_identical_to_the_one_candidate_kernel_at_scale(gpu, name, B, monkeypatch):
+    """What a launch of more than 4096 candidates runs by default, against the one-candidate-per-lane kernel on the same
+    inputs: rewards, tracked positions and the final link states of every candidate."""
+    import torch
+    from mbd_hip.envs import get_env
+    env = get_env(name)
+    st = env.reset(gpu.prng_key(4))
+    rng = np.random.default_rng(B)
+    us = np.clip(rng.normal(size=(B, 50, env.action_size)) * 0.7, -1.3, 1.3).astype(np.float32)
+    want = env.xref is not None
+    res = {}
+    for k in ("0", "auto"):
+        if k == "auto":
+            monkeypatch.delenv("MBD_PK2", raising=False)
+        else:
+            monkeypatch.setenv("MBD_PK2", k)
+        out = env.rollout(st, us, want_xpos=want, want_final=True)
+        res[k] = [o.cpu().numpy() for o in out]
+    for a, b in zip(res["0"], res["auto"]):
+        assert np.isfinite(a).all() and np.array_equal(a, b)

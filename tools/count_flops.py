@@ -30,6 +30,10 @@ INSTANCES = {
     "halfcheetah_planar": "planar:8,2,1,-3,1,2",
     "walker2d_planar": "planar:8,2,1,-3,0,1,20",
     "cartpole_planar": "planar:4,0,1,0,2,5,4",
+    # two candidates per lane (mbd_pk2.h: rollout_pk2_kernel<MAXCOL, RK, NFR>): the counts are per candidate PAIR
+    "humanoidrun_pk2": "pk2:1,0,7",
+    "humanoidtrack_pk2": "pk2:1,3,5",
+    "humanoidstandup_pk2": "pk2:5,4,7",
 }
 
 
@@ -40,6 +44,8 @@ def count(targs):
         kern, hdr = "rollout_kernel", "mbd_kernels.h"
         if targs.startswith("planar:"):
             kern, hdr, targs = "rollout_planar_kernel", "mbd_planar.h", targs[len("planar:"):]
+        if targs.startswith("pk2:"):
+            kern, hdr, targs = "rollout_pk2_kernel", "mbd_pk2.h", targs[len("pk2:"):]
         with open(src, "w") as f:
             f.write(f'#include "{csrc}/{hdr}"\ntemplate __global__ void mbd::{kern}<{targs}>(mbd::RolloutParams);\n')
         out = os.path.join(td, "k.s")
@@ -47,7 +53,7 @@ def count(targs):
                         "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", *os.environ.get("MBD_COUNT_DEFS", "").split(),
                         "-S", "--cuda-device-only", src, "-o", out], check=True, capture_output=True)
         body = open(out).read().split("\n")
-    start = [i for i, l in enumerate(body) if re.match(r"^_ZN3mbd\d+rollout_(planar_)?kernel.*:", l)][0]
+    start = [i for i, l in enumerate(body) if re.match(r"^_ZN3mbd\d+rollout_(planar_|pk2_)?kernel.*:", l)][0]
     end = [i for i, l in enumerate(body) if i > start and ".Lfunc_end" in l][0]
     meta = "\n".join(body[end:])
     body = body[start:end]
@@ -100,6 +106,8 @@ def count(targs):
         unroll = int(targs.split(",")[6]) // 2
     if kern == "rollout_kernel" and len(targs.split(",")) >= 16 and int(targs.split(",")[15]) > 0:
         unroll = int(targs.split(",")[15]) // 2
+    if kern == "rollout_pk2_kernel":
+        unroll = int(targs.split(",")[2]) // 2 if int(targs.split(",")[2]) > 1 else 2
     if unroll > 1:
         c = collections.Counter({k: v / unroll for k, v in c.items()})
         flops, slots, nops = flops / unroll, slots / unroll, nops
@@ -108,6 +116,7 @@ def count(targs):
            "valu_per_substep": sum(v for k, v in c.items() if k.startswith("v_")),
            "lds_instr_per_substep": sum(v for k, v in c.items() if k.startswith("ds_")),
            "dpp_per_substep": sum(v for k, v in c.items() if "dpp" in k),
+           "agpr_moves_per_substep": sum(v for k, v in c.items() if k.startswith("v_accvgpr")),
            "s_nop_per_substep": c.get("s_nop", 0), "s_waitcnt_per_substep": c.get("s_waitcnt", 0),
            "fp32_flops_per_lane_substep": flops, "vgpr": int(vg.group(1)) if vg else None,
            "scratch_bytes": int(sc.group(1)) if sc else None}
