@@ -317,6 +317,30 @@ int mbd_plan_peek(mbd_plan* plan, float* Y0s_out, float* rewss_out, float* weigh
 int mbd_plan_kernel_time(mbd_plan* plan, float* avg_ms_out, int* count_out, int reset);
 int mbd_plan_enable_timing(mbd_plan* plan, int enable);
 
+/* ------------------------------------------------------------------------------------------------ */
+/* sweeps — replaces the loops of mbd/scripts/run_mbd.py (:17-39 eight seeds, :42-64 eight           */
+/* temperatures): P independent MBD plans of ONE env with the same (Nsample, Hsample, Ndiffuse,      */
+/* beta0, betaT, enable_demo) advanced in lockstep, ONE rollout launch over the P * Nsample          */
+/* candidates and ONE score + weighted-mean launch per diffusion step.  Seeds (keys, start states)   */
+/* and temperatures may differ per plan.  Every plan's result is bit-identical to mbd_plan_run on    */
+/* that plan alone.                                                                                  */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct mbd_sweep mbd_sweep;
+#define MBD_SWEEP_MAX_PLANS 32
+/* cfg: as for mbd_plan_create (update_method 0, unsharded; Nsample * 4 bytes <= 48 KB: larger plans fill the
+ * chip on their own — run them as plans).  temps: [n_plans] temp_sample per plan, or NULL: cfg->temp_sample. */
+int mbd_sweep_create(mbd_env* env, const mbd_plan_config* cfg, int n_plans, const float* temps, mbd_sweep** out);
+int mbd_sweep_destroy(mbd_sweep* sweep);
+/* state_init of plan k (HOST, state_size floats) */
+int mbd_sweep_set_state0(mbd_sweep* sweep, int k, const float* state0);
+/* the P reverse loops + final evaluations (mbd_planner.py:138-148,179-180).  keys: [n_plans][2] = rng_exp of each
+ * plan (:150).  HOST outputs, any may be NULL: mu_0ts_out [n_plans][Ndiffuse-1][H][Nu], rew_means_out
+ * [n_plans][Ndiffuse-1], rew_final_out [n_plans]; loop_seconds_out: wall time of the lockstep loop.  Synchronous. */
+int mbd_sweep_run(mbd_sweep* sweep, const uint32_t* keys, float* mu_0ts_out, float* rew_means_out,
+                  float* rew_final_out, double* loop_seconds_out);
+/* average milliseconds of the sweep's rollout launches since the last reset (hipEvents on the launch stream) */
+int mbd_sweep_kernel_time(mbd_sweep* sweep, int enable, float* avg_ms_out, int* count_out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -219,7 +219,8 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
   const int rkind = RK >= 0 ? RK : Mg->reward_kind;
 
   // ---- state: both candidates start from the same state0 --------------------------------------------------
-  const float* s0 = P.state0 + l * MBD_LINK_STATE;
+  const int pl = plan_of(P, bA);  // (sweeps: plans hold an even number of candidates, a pair never straddles two)
+  const float* s0 = P.state0 + (size_t)pl * P.plan_state_stride + l * MBD_LINK_STATE;
   v3 p1 = mk3(s0[0], s0[1], s0[2]);
   q4 r1 = q4{s0[3], s0[4], s0[5], s0[6]};
   v3 v1 = mk3(s0[7], s0[8], s0[9]);
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
   const float* uA = P.us + (size_t)bA * H * Nu;
   const float* uB = P.us + (size_t)bB * H * Nu;
   const bool lazy = P.ybar != nullptr;
-  const float* __restrict__ yb_row = lazy ? P.ybar : P.us;
+  const float* __restrict__ yb_row = lazy ? P.ybar + (size_t)pl * P.plan_ybar_stride : P.us;
   const float sigma = P.sigma;
   auto cand = [&](f2 e, float yb) {  // (mul, add: the sampler's roundings)
     const f2 c = fclip2(e * splat(sigma) + splat(yb), -1.0f, 1.0f);

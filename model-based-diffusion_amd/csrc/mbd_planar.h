@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   };
 
   // ---- state -------------------------------------------------------------------------------------------
-  const float* s0 = P.state0 + l * MBD_LINK_STATE;
+  const int pl = plan_of(P, b);
+  const float* s0 = P.state0 + (size_t)pl * P.plan_state_stride + l * MBD_LINK_STATE;
   float px = s0[0], pz = s0[2], qw = s0[3], qy = s0[5], vx = s0[7], vz = s0[9], om = s0[11];
   if (!link_ok) { px = pz = 0.0f; qw = 1.0f; qy = 0.0f; vx = vz = om = 0.0f; }
 
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   // lazy candidates (wave-uniform; RolloutParams): u_row holds normals, the action is clip(eps * sigma + Ybar_i, -1, 1)
   // (branch-free, like rollout_kernel: unconditional Ybar loads — from P.us itself, ignored, when not lazy — and selects)
   const bool lazy = P.ybar != nullptr;
-  const float* __restrict__ yb_row = lazy ? P.ybar : P.us;
+  const float* __restrict__ yb_row = lazy ? P.ybar + (size_t)pl * P.plan_ybar_stride : P.us;
   const float sigma = P.sigma;
   auto cand = [&](float e, float yb) {
     const float c = fclip(e * sigma + yb, -1.0f, 1.0f);

@@ -42,6 +42,7 @@ EXPORTS = [
     "mbd_plan_schedule", "mbd_plan_set_state0", "mbd_plan_sample_rollout", "mbd_plan_prefetch_noise", "mbd_plan_score_update",
     "mbd_plan_set_sigma", "mbd_plan_get_sigma", "mbd_plan_reverse_once", "mbd_plan_run", "mbd_plan_eval", "mbd_plan_peek", "mbd_plan_kernel_time",
     "mbd_plan_enable_timing",
+    "mbd_sweep_create", "mbd_sweep_destroy", "mbd_sweep_set_state0", "mbd_sweep_run", "mbd_sweep_kernel_time",
 ]
 
 _lib = None
@@ -103,6 +104,11 @@ def load() -> C.CDLL:
     lib.mbd_plan_peek.argtypes = [_vp, _vp, _vp, _vp]
     lib.mbd_plan_kernel_time.argtypes = [_vp, _fp, C.POINTER(_i), _i]
     lib.mbd_plan_enable_timing.argtypes = [_vp, _i]
+    lib.mbd_sweep_create.argtypes = [_vp, C.POINTER(PlanConfig), _i, _vp, C.POINTER(_vp)]
+    lib.mbd_sweep_destroy.argtypes = [_vp]
+    lib.mbd_sweep_set_state0.argtypes = [_vp, _i, _vp]
+    lib.mbd_sweep_run.argtypes = [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)]
+    lib.mbd_sweep_kernel_time.argtypes = [_vp, _i, _fp, C.POINTER(_i)]
     _lib = lib
     return lib
 

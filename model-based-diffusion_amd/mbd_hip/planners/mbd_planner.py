@@ -55,6 +55,64 @@ def apply_recommended(args: Args) -> None:
         print(f"override temp_sample to {args.temp_sample}")
 
 
+class Sweep:
+    """Owner of an ``mbd_sweep`` handle: several MBD plans of one env (same sizes and schedule; seeds, start states and
+    temperatures may differ) advanced in lockstep — ONE rollout launch over all their candidates and ONE score launch per
+    diffusion step (mbd/scripts/run_mbd.py:17-64).  Every plan's result is bit-identical to ``Plan.run`` on its own."""
+
+    def __init__(self, env, args, n_plans: int, temps=None, literal_score: bool = True):
+        self.lib = _capi.load()
+        self.env = env
+        cfg = _capi.PlanConfig()
+        cfg.Nsample, cfg.Hsample, cfg.Ndiffuse = args.Nsample, args.Hsample, args.Ndiffuse
+        cfg.temp_sample = args.temp_sample
+        cfg.beta0, cfg.betaT = args.beta0, args.betaT
+        cfg.enable_demo = int(args.enable_demo)
+        cfg.update_method = 0
+        cfg.prng_impl = prng_impl()
+        cfg.shard_begin, cfg.shard_count = 0, args.Nsample
+        cfg.literal_score = int(literal_score)
+        self.cfg, self.P = cfg, int(n_plans)
+        t = None if temps is None else np.ascontiguousarray(temps, np.float32).reshape(self.P)
+        h = C.c_void_p()
+        _capi.check(self.lib.mbd_sweep_create(env.handle, C.byref(cfg), self.P, None if t is None else _capi.np_ptr(t),
+                                              C.byref(h)))
+        self.h = h
+        self.Nd, self.H, self.Nu = cfg.Ndiffuse, args.Hsample, env.action_size
+
+    def set_state0(self, k: int, state):
+        st = np.ascontiguousarray(state.pipeline_state, np.float32).reshape(-1)
+        _capi.check(self.lib.mbd_sweep_set_state0(self.h, int(k), _capi.np_ptr(st)))
+
+    def run(self, keys):
+        """keys [P, 2] = rng_exp of every plan.  Returns (mu_0ts [P, Nd-1, H, Nu], rew_means [P, Nd-1], rew_final [P],
+        seconds of the lockstep loop)."""
+        k = np.ascontiguousarray(keys, np.uint32).reshape(self.P, 2)
+        mu = np.zeros((self.P, self.Nd - 1, self.H, self.Nu), np.float32)
+        rm = np.zeros((self.P, self.Nd - 1), np.float32)
+        rf = np.zeros(self.P, np.float32)
+        secs = C.c_double()
+        _capi.check(self.lib.mbd_sweep_run(self.h, _capi.np_ptr(k), _capi.np_ptr(mu), _capi.np_ptr(rm), _capi.np_ptr(rf),
+                                           C.byref(secs)))
+        return mu, rm, rf, secs.value
+
+    def kernel_time(self, enable=True):
+        ms, n = C.c_float(), C.c_int()
+        _capi.check(self.lib.mbd_sweep_kernel_time(self.h, int(enable), C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    def close(self):
+        if self.h is not None:
+            self.lib.mbd_sweep_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class Plan:
     """Thin owner of an ``mbd_plan`` handle."""
 

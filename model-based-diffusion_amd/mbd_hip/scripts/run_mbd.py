@@ -1,10 +1,12 @@
 """Drop-in for mbd/scripts/run_mbd.py (:17-64): the 8-seed sweep and the 8-temperature sweep.
 
 The reference runs the plans one after another and times each run end to end (`time()` around
-`run_diffusion`, :21,34).  Here the independent plans are ENQUEUED CONCURRENTLY: one `mbd_plan` and one
-HIP stream per plan, the reverse loops stepped round-robin from the host, so that at N=1024 (256
-wavefronts per rollout launch — a quarter of the chip's SIMDs) eight plans overlap on the GPU instead of
-queueing.  Results are bit-identical to running the plans sequentially (tests/test_gpu_parity.py).
+`run_diffusion`, :21,34).  Here the independent plans of a sweep run TOGETHER: plans of one env with the same
+sizes and schedule — both of the reference's sweeps — go through `mbd_sweep_*` in lockstep, one rollout launch over
+all their candidates and one score launch per diffusion step (at N=1024 a plan's rollout is 256 wavefronts, a quarter
+of the chip's SIMDs; eight of them fill it); anything else (mixed sizes) is enqueued concurrently, one `mbd_plan`
+and one HIP stream per plan, stepped round-robin from the host.  Results are bit-identical to running the plans
+sequentially either way (tests/test_gpu_parity.py).
 """
 from __future__ import annotations
 
@@ -29,10 +31,58 @@ class Args:
     env_name: str = "ant"
 
 
-def run_concurrent(plan_args, device: int = 0):
-    """Run several independent MBD plans (a list of mbd_planner.Args) concurrently on one GPU.
-    Returns (rew_final list, mu_0ts list, wall seconds of the whole batch)."""
+def _resolved(a):
+    """a copy of the plan's Args with the recommended overrides applied (mbd_planner.py:64-69), quietly"""
+    import contextlib
+    import io
+    a = replace(a)
+    with contextlib.redirect_stdout(io.StringIO()):
+        apply_recommended(a)
+    return a
+
+
+def _batchable(plan_args):
+    """One env, one set of sizes / schedule, <= 32 plans of <= 12288 candidates: what mbd_sweep_* takes."""
+    from dataclasses import asdict
+    ds = []
+    for a in plan_args:
+        d = asdict(_resolved(a))
+        for k in ("seed", "temp_sample", "not_render"):
+            d.pop(k, None)
+        ds.append(d)
+    return (1 < len(plan_args) <= 32 and all(d == ds[0] for d in ds) and ds[0]["Nsample"] * 4 <= 48 * 1024
+            and ds[0]["env_name"] not in ("car2d", "pushT"))
+
+
+def run_sweep(plan_args, device: int = 0):
+    """The plans as ONE mbd_sweep (lockstep, one rollout launch per diffusion step).  Same returns as run_concurrent."""
+    from ..planners.mbd_planner import Sweep
+    impl = prng_impl()
+    a0 = replace(plan_args[0])
+    apply_recommended(a0)
+    env = get_env(a0.env_name, device=device)
+    sweep = Sweep(env, a0, len(plan_args), temps=[_resolved(a).temp_sample for a in plan_args])
+    keys = []
+    for k, a in enumerate(plan_args):
+        rng = _capi.prng_key(a.seed)  # mbd_planner.py:40
+        rng, rng_reset = _capi.prng_split(rng, 2, impl)  # :79
+        sweep.set_state0(k, env.reset(rng_reset))
+        rng_exp, _ = _capi.prng_split(rng, 2, impl)  # :150
+        keys.append(rng_exp)
+    mu, _, rews, secs = sweep.run(np.array(keys, np.uint32))  # (secs: the lockstep loop, like run_concurrent's)
+    sweep.close()
+    return [float(r) for r in rews], [m for m in mu], secs
+
+
+def run_concurrent(plan_args, device: int = 0, batched: bool | None = None):
+    """Run several independent MBD plans (a list of mbd_planner.Args) together on one GPU: as one sweep (lockstep, one
+    launch per step) when they share env, sizes and schedule (batched=None decides; True / False force), as concurrent
+    plans on separate streams otherwise.  Returns (rew_final list, mu_0ts list, wall seconds of the whole batch)."""
     import torch
+    if batched is None:
+        batched = _batchable(plan_args)
+    if batched:
+        return run_sweep(plan_args, device)
     dev = torch.device("cuda", device)
     impl = prng_impl()
     jobs = []

@@ -1039,3 +1039,57 @@ def test_pk2_is_bit_identical_to_the_one_candidate_kernel_at_scale(gpu, name, B,
         res[k] = [o.cpu().numpy() for o in out]
     for a, b in zip(res["0"], res["auto"]):
         assert np.isfinite(a).all() and np.array_equal(a, b)
+
+
+# ---- sweeps: several plans in one launch per step (mbd_sweep_*) ------------------------------------------------------
+@pytest.mark.parametrize("name,N,H,Nd,demo,pk2", [("humanoidrun", 256, 50, 12, False, None), ("humanoidrun", 96, 20, 8, False, "1"),
+                                                  ("humanoidrun", 33, 12, 6, False, "1"), ("humanoidtrack", 128, 50, 8, True, None),
+                                                  ("humanoidtrack", 64, 50, 6, True, "1"), ("hopper", 96, 50, 10, False, None),
+                                                  ("halfcheetah", 50, 30, 7, False, None), ("ant", 40, 20, 6, False, None)])
+def test_sweep_equals_the_plans_run_alone(gpu, name, N, H, Nd, demo, pk2, monkeypatch):
+    """SURVEY §8(f) N3 as ONE batched launch per diffusion step (mbd/scripts/run_mbd.py:17-39): every plan of a
+    seed sweep — its own key chain and start state — comes out of mbd_sweep_run exactly as out of run_diffusion on its
+    own: mu_0ts, per-step mean rewards and the final reward, bit for bit.  pk2 = "1": the sweep's rollout through the
+    two-candidates-per-lane kernel (an odd N falls back to the one-candidate kernel: a pair must not straddle two
+    plans)."""
+    from mbd_hip.planners.mbd_planner import Args, run_diffusion
+    from mbd_hip.scripts.run_mbd import run_concurrent
+    plans = [Args(seed=s, env_name=name, Nsample=N, Hsample=H, Ndiffuse=Nd, temp_sample=0.1, enable_demo=demo,
+                  disable_recommended_params=True, not_render=True) for s in range(5)]
+    if pk2 is not None:
+        monkeypatch.setenv("MBD_PK2", pk2)
+    rews, mus, _ = run_concurrent(plans, batched=True)
+    monkeypatch.delenv("MBD_PK2", raising=False)
+    for a, r, mu in zip(plans, rews, mus):
+        r_seq, det = run_diffusion(a, return_details=True)
+        assert np.array_equal(mu, det["mu_0ts"]), (name, a.seed)
+        assert np.float32(r) == np.float32(r_seq)
+
+
+def test_temperature_sweep_equals_the_plans_run_alone(gpu):
+    """run_mbd.py:42-64: eight temperatures at seed 0 — one sweep whose plans differ in temp_sample only."""
+    from mbd_hip.planners.mbd_planner import Args, run_diffusion
+    from mbd_hip.scripts.run_mbd import run_concurrent, _batchable
+    temps = [0.01, 0.03, 0.06, 0.1, 0.2, 0.4, 0.6, 0.8]
+    plans = [Args(seed=0, env_name="humanoidrun", Nsample=128, Hsample=30, Ndiffuse=9, temp_sample=t,
+                  disable_recommended_params=True, not_render=True) for t in temps]
+    assert _batchable(plans)
+    rews, mus, _ = run_concurrent(plans)
+    assert len({np.asarray(m).tobytes() for m in mus}) == len(temps)  # (the temperature does change the plan)
+    for a, r, mu in zip(plans, rews, mus):
+        r_seq, det = run_diffusion(a, return_details=True)
+        assert np.array_equal(mu, det["mu_0ts"]) and np.float32(r) == np.float32(r_seq)
+
+
+def test_sweep_rejects_what_it_does_not_batch(gpu):
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.mbd_planner import Args, Sweep
+    env = get_env("humanoidrun")
+    a = Args(env_name="humanoidrun", Nsample=16384, Hsample=10, Ndiffuse=4, disable_recommended_params=True)
+    with pytest.raises(gpu.MbdError):
+        Sweep(env, a, 2)  # plans that fill the chip on their own
+    a.Nsample = 64
+    with pytest.raises(gpu.MbdError):
+        Sweep(env, a, 33)  # more than MBD_SWEEP_MAX_PLANS
+    with pytest.raises(gpu.MbdError):
+        Sweep(get_env("car2d"), Args(env_name="car2d", Nsample=64, Hsample=10, Ndiffuse=4), 2)

@@ -19,7 +19,7 @@ import tempfile
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 STRADDLE, PROMOTE = 0.8, 0.125  # issue slots: a straddling 8-byte instruction; 4 more bytes of code (1 slot per 32)
-TARGET_FUNCS = ("3mbd14rollout_kernel", "3mbd21rollout_planar_kernel")  # (mangled: not car2d_rollout_kernel)
+TARGET_FUNCS = ("3mbd14rollout_kernel", "3mbd21rollout_planar_kernel", "3mbd18rollout_pk2_kernel")  # (mangled: not car2d_rollout_kernel)
 
 
 def _is_instr(line):
