@@ -56,11 +56,12 @@ __device__ __forceinline__ q4x2 qnormalize2(q4x2 q) {
   f2 n2 = fma2(q.w, q.w, fma2(q.x, q.x, fma2(q.y, q.y, q.z * q.z)));
   f2 e = n2 - splat(1.0f);
   f2 inv = fma2(fma2(fma2(fma2(splat(0.2734375f), e, splat(-0.3125f)), e, splat(0.375f)), e, splat(-0.5f)), e, splat(1.0f));
-  const bool far0 = fabs_(e.x) > 0.05f, far1 = fabs_(e.y) > 0.05f;
-  if (__builtin_expect(far0 || far1, 0)) {
-    const float i0 = 1.0f / fsqrt(n2.x), i1 = 1.0f / fsqrt(n2.y);
-    inv = mk2(far0 ? i0 : inv.x, far1 ? i1 : inv.y);
-  }
+  // (one cold block per half, the one-candidate kernel's pattern: both sit out of line.  As ONE block for the pair —
+  // `far0 || far1`, selects inside — it compiled to an if / else whose common side left by a TAKEN branch per substep.)
+  float i0 = inv.x, i1 = inv.y;
+  if (__builtin_expect(fabs_(e.x) > 0.05f, 0)) i0 = 1.0f / fsqrt(n2.x);
+  if (__builtin_expect(fabs_(e.y) > 0.05f, 0)) i1 = 1.0f / fsqrt(n2.y);
+  inv = mk2(i0, i1);
   return q4x2{q.w * inv, q.x * inv, q.y * inv, q.z * inv};
 }
 __device__ __forceinline__ q4x2 qrotvec_raw2(q4x2 q, v3x2 th) {
@@ -130,22 +131,46 @@ __device__ __forceinline__ JointFramesP joint_frames_p(const JointConst& jc, v3x
   return f;
 }
 
-// children -> parent sums and the parent's pose, per half, through the scalar kernel's DPP blocks
+// children -> parent sums and the parent's pose for both halves in ONE block each (one hazard s_nop per exchange; the
+// one-candidate kernel's forms, dpp_acc6x3 / dpp_fetch7<1, -4, -6>, per 32-bit half: same operations, same order)
+#define MBD_PF(R, X, M, MOD) "v_fmac_f32_dpp %" #R ", %" #X ", %" #M " " MOD " row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+#define MBD_PF12(MOD, M)                                                                                         \
+  MBD_PF(0, 12, M, MOD) MBD_PF(1, 13, M, MOD) MBD_PF(2, 14, M, MOD) MBD_PF(3, 15, M, MOD) MBD_PF(4, 16, M, MOD)  \
+  MBD_PF(5, 17, M, MOD) MBD_PF(6, 18, M, MOD) MBD_PF(7, 19, M, MOD) MBD_PF(8, 20, M, MOD) MBD_PF(9, 21, M, MOD)  \
+  MBD_PF(10, 22, M, MOD) MBD_PF(11, 23, M, MOD)
 __device__ __forceinline__ void dpp_acc6x3_p(v3x2& a, v3x2& b, v3x2 x, v3x2 y, float m0, float m1, float m2) {
-  v3 a0 = lo3(a), a1 = hi3(a), b0 = lo3(b), b1 = hi3(b);
-  dpp_acc6x3(a0, b0, lo3(x), lo3(y), m0, m1, m2);
-  dpp_acc6x3(a1, b1, hi3(x), hi3(y), m0, m1, m2);
-  a = pack3(a0, a1);
-  b = pack3(b0, b1);
+  float a0 = a.x.x, a1 = a.y.x, a2 = a.z.x, a3 = b.x.x, a4 = b.y.x, a5 = b.z.x;
+  float a6 = a.x.y, a7 = a.y.y, a8 = a.z.y, a9 = b.x.y, a10 = b.y.y, a11 = b.z.y;
+  asm("s_nop 1\n\t" MBD_PF12("row_shr:1", 24) MBD_PF12("row_shl:4", 25) MBD_PF12("row_shl:6", 26)
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9), "+v"(a10),
+        "+v"(a11)
+      : "v"(x.x.x), "v"(x.y.x), "v"(x.z.x), "v"(y.x.x), "v"(y.y.x), "v"(y.z.x), "v"(x.x.y), "v"(x.y.y), "v"(x.z.y),
+        "v"(y.x.y), "v"(y.y.y), "v"(y.z.y), "v"(m0), "v"(m1), "v"(m2));
+  a = v3x2{mk2(a0, a6), mk2(a1, a7), mk2(a2, a8)};
+  b = v3x2{mk2(a3, a9), mk2(a4, a10), mk2(a5, a11)};
 }
+#undef MBD_PF12
+#define MBD_PF14(MOD, M)                                                                                         \
+  MBD_PF(0, 14, M, MOD) MBD_PF(1, 15, M, MOD) MBD_PF(2, 16, M, MOD) MBD_PF(3, 17, M, MOD) MBD_PF(4, 18, M, MOD)  \
+  MBD_PF(5, 19, M, MOD) MBD_PF(6, 20, M, MOD) MBD_PF(7, 21, M, MOD) MBD_PF(8, 22, M, MOD) MBD_PF(9, 23, M, MOD)  \
+  MBD_PF(10, 24, M, MOD) MBD_PF(11, 25, M, MOD) MBD_PF(12, 26, M, MOD) MBD_PF(13, 27, M, MOD)
 __device__ __forceinline__ void dpp_fetch7_p(v3x2 p, q4x2 r, float m0, float m1, float m2, v3x2& Pp, q4x2& Pr) {
-  v3 p0, p1;
-  q4 r0, r1;
-  dpp_fetch7<1, -4, -6>(lo3(p), lo4(r), m0, m1, m2, p0, r0);
-  dpp_fetch7<1, -4, -6>(hi3(p), hi4(r), m0, m1, m2, p1, r1);
-  Pp = pack3(p0, p1);
-  Pr = pack4(r0, r1);
+  float o0 = dpp_from<1>(p.x.x) * m0, o1 = dpp_from<1>(p.y.x) * m0, o2 = dpp_from<1>(p.z.x) * m0;
+  float o3 = dpp_from<1>(r.w.x) * m0, o4 = dpp_from<1>(r.x.x) * m0, o5 = dpp_from<1>(r.y.x) * m0;
+  float o6 = dpp_from<1>(r.z.x) * m0;
+  float o7 = dpp_from<1>(p.x.y) * m0, o8 = dpp_from<1>(p.y.y) * m0, o9 = dpp_from<1>(p.z.y) * m0;
+  float o10 = dpp_from<1>(r.w.y) * m0, o11 = dpp_from<1>(r.x.y) * m0, o12 = dpp_from<1>(r.y.y) * m0;
+  float o13 = dpp_from<1>(r.z.y) * m0;
+  asm("s_nop 1\n\t" MBD_PF14("row_shr:4", 28) MBD_PF14("row_shr:6", 29)
+      : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(o4), "+v"(o5), "+v"(o6), "+v"(o7), "+v"(o8), "+v"(o9), "+v"(o10),
+        "+v"(o11), "+v"(o12), "+v"(o13)
+      : "v"(p.x.x), "v"(p.y.x), "v"(p.z.x), "v"(r.w.x), "v"(r.x.x), "v"(r.y.x), "v"(r.z.x), "v"(p.x.y), "v"(p.y.y),
+        "v"(p.z.y), "v"(r.w.y), "v"(r.x.y), "v"(r.y.y), "v"(r.z.y), "v"(m1), "v"(m2));
+  Pp = v3x2{mk2(o0, o7), mk2(o1, o8), mk2(o2, o9)};
+  Pr = q4x2{mk2(o3, o10), mk2(o4, o11), mk2(o5, o12), mk2(o6, o13)};
 }
+#undef MBD_PF14
+#undef MBD_PF
 
 // MAXCOL: most sphere colliders on one link (1: humanoidrun / humanoidtrack, 5: humanoidstandup)
 // RK, NFR: reward kind and n_frames as compile-time constants (-1 / 0: read at run time), as in rollout_kernel
