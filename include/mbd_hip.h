@@ -255,7 +255,10 @@ typedef struct mbd_plan_config {
                             1 = mppi (softmax_update), 2 = cma-es, 3 = cem. For these Ndiffuse plays
                             Nrefine (:28), sigma is a carried scalar starting at 1.0 (:131), the
                             standardisation has no zero-std guard (:123) and demos are not used.      */
-  int32_t reserved[4];
+  int32_t shares_device; /* 1: other plans run on this GPU at the same time (plans of a sweep on separate streams):
+                            the plan then generates each step's normals in front of its rollout instead of one step
+                            ahead in workgroups / on a stream the other plans need (results identical either way)  */
+  int32_t reserved[3];
 } mbd_plan_config;
 
 int mbd_plan_create(mbd_env* env, const mbd_plan_config* cfg, mbd_plan** out);
@@ -285,7 +288,9 @@ int mbd_plan_prefetch_noise(mbd_plan* plan, const uint32_t key_next[2], void* st
 /* phase 2 (mbd_planner.py:111-135): from ALL N rewards (after the all-gather) standardise, demo
  * blend, softmax, weighted mean over all N candidates (noise regenerated from the counter-based PRNG,
  * so the result is bit-identical on every rank and for every shard layout), score update.
- * Writes d_Ybar_im1 [H][Nu] and d_rew_mean [1] (= rews.mean(), :135). async on stream. */
+ * Writes d_Ybar_im1 [H][Nu] and d_rew_mean [1] (= rews.mean(), :135). async on stream.
+ * (The phases of a plan may be issued on different streams: the library orders each call behind the plan's previous
+ * one with an event when the stream changes — the normals prepared by one step's launch are read by the next.) */
 int mbd_plan_score_update(mbd_plan* plan, int i, const uint32_t key_sample[2], const float* d_Ybar_i,
                           const float* d_rews_all, const float* d_logpd_all, float* d_Ybar_im1,
                           float* d_rew_mean, void* stream);

@@ -31,7 +31,7 @@ class PlanConfig(C.Structure):
                 ("temp_sample", C.c_float), ("beta0", C.c_float), ("betaT", C.c_float),
                 ("enable_demo", C.c_int32), ("prng_impl", C.c_int32), ("shard_begin", C.c_int32),
                 ("shard_count", C.c_int32), ("literal_score", C.c_int32), ("update_method", C.c_int32),
-                ("reserved", C.c_int32 * 4)]
+                ("shares_device", C.c_int32), ("reserved", C.c_int32 * 3)]
 
 
 EXPORTS = [

@@ -117,7 +117,7 @@ class Plan:
     """Thin owner of an ``mbd_plan`` handle."""
 
     def __init__(self, env, args, shard_begin: int = 0, shard_count: int = None, literal_score: bool = True,
-                 update_method: int = 0):
+                 update_method: int = 0, shares_device: bool = False):
         self.lib = _capi.load()
         self.env = env
         cfg = _capi.PlanConfig()
@@ -131,6 +131,7 @@ class Plan:
         cfg.shard_begin = shard_begin
         cfg.shard_count = args.Nsample if shard_count is None else shard_count
         cfg.literal_score = int(literal_score)
+        cfg.shares_device = int(shares_device)  # other plans run on this GPU at the same time (concurrent sweeps)
         self.cfg = cfg
         h = C.c_void_p()
         _capi.check(self.lib.mbd_plan_create(env.handle, C.byref(cfg), C.byref(h)))
@@ -209,6 +210,7 @@ class HostProgress:
         self.t = torch.full((max(n, 1),), float("nan"), dtype=torch.float32).pin_memory()
         self.v = self.t.numpy()
         self.device = device
+        self.gave_up = False  # a slot stayed NaN past the timeout (a diverged plan's mean IS NaN): synchronise from then on
 
     def ptr(self, k: int) -> int:
         return self.t.data_ptr() + 4 * k
@@ -219,12 +221,16 @@ class HostProgress:
     def wait(self, k: int, timeout_s: float = 2.0) -> float:
         import torch
         v, t0, spins = self.v, None, 0
+        if self.gave_up:  # (a genuinely NaN mean looks like "not written yet": do not spin the timeout again every step)
+            torch.cuda.synchronize(self.device)
+            return float(v[k])
         while v[k] != v[k]:  # NaN: not written yet
             spins += 1
             if spins & 0xfff == 0:
                 t0 = t0 or time.perf_counter()
                 if time.perf_counter() - t0 > timeout_s:
                     torch.cuda.synchronize(self.device)
+                    self.gave_up = True
                     break
         return float(v[k])
 
@@ -270,8 +276,16 @@ def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bo
     import torch
     import torch.distributed as dist
 
-    world = dist.get_world_size(group) if dist.is_initialized() else 1
     N, sh = plan.cfg.Nsample, plan.cfg.shard_count
+    # the exchange follows the PLAN's shard layout, not whatever process group happens to be initialised: an unsharded
+    # plan (force_single under torchrun) must not all-gather — it would score rank 0's rewards on every rank
+    world = N // sh
+    if sh * world != N:
+        raise ValueError(f"shard_count={sh} does not divide Nsample={N}")
+    if world > 1:
+        group_world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if group_world != world:
+            raise ValueError(f"the plan is sharded over {world} ranks but the process group has {group_world}")
     demo = bool(plan.cfg.enable_demo)
     rows = 2 if demo else 1
     HNu = plan.H * plan.Nu

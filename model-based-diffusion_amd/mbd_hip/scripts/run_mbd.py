@@ -94,7 +94,7 @@ def run_concurrent(plan_args, device: int = 0, batched: bool | None = None):
         rng, rng_reset = _capi.prng_split(rng, 2, impl)  # :79
         state_init = env.reset(rng_reset)
         rng_exp, _ = _capi.prng_split(rng, 2, impl)  # :150
-        plan = Plan(env, a)
+        plan = Plan(env, a, shares_device=len(plan_args) > 1)
         plan.set_state0(state_init)
         HNu = a.Hsample * env.action_size
         jobs.append(dict(args=a, env=env, plan=plan, stream=torch.cuda.Stream(dev),

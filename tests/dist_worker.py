@@ -35,9 +35,19 @@ def main():
     rew1, det1 = run_diffusion(Args(**vars(a)), device=0, return_details=True, force_single=True)  # unsharded
     ok = bool(np.array_equal(det["mu_0ts"], det1["mu_0ts"]) and np.array_equal(det["rew_means"], det1["rew_means"])
               and np.float32(rew) == np.float32(rew1))
+    # round-2 advice: an UNSHARDED plan stepped through the Python loop (progress callback) under an initialised
+    # multi-rank group must not touch the group — with a different seed per rank a stray all-gather would score rank
+    # 0's rewards on every rank (or hang)
+    b = Args(**{**vars(a), "seed": 11 + rank, "Ndiffuse": min(Nd, 6)})
+    seen = []
+    rew2, det2 = run_diffusion(Args(**vars(b)), device=0, return_details=True, force_single=True,
+                               progress=lambda i, r: seen.append(r))
+    rew3, det3 = run_diffusion(Args(**vars(b)), device=0, return_details=True, force_single=True)
+    ok_single = bool(np.array_equal(det2["mu_0ts"], det3["mu_0ts"]) and np.float32(rew2) == np.float32(rew3)
+                     and len(seen) == b.Ndiffuse - 1 and np.array_equal(np.float32(seen), det3["rew_means"]))
     np.save(os.path.join(out, f"mu_rank{rank}.npy"), det["mu_0ts"])
     with open(os.path.join(out, f"rank{rank}.json"), "w") as f:
-        json.dump({"rank": rank, "world": world, "equal_to_unsharded": ok, "rew": float(rew), "rew_unsharded": float(rew1),
+        json.dump({"rank": rank, "world": world, "equal_to_unsharded": ok, "force_single_progress_ok": ok_single, "rew": float(rew), "rew_unsharded": float(rew1),
                    "steps_per_sec_sharded": det["steps_per_sec"], "steps_per_sec_unsharded": det1["steps_per_sec"],
                    "phase_ms": det.get("phase_ms")}, f)
     dist.barrier()

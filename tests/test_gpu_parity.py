@@ -728,6 +728,7 @@ def test_two_real_ranks_run_the_sharded_product_path(gpu, tmp_path):
     and final reward must equal the unsharded plan's bit for bit, and each other's."""
     res, mus = _run_two_ranks(tmp_path, "humanoidrun", 1024, 50, 12, 0.1, False)
     assert all(r["world"] == 2 and r["equal_to_unsharded"] for r in res), res
+    assert all(r["force_single_progress_ok"] for r in res), res  # (unsharded plans never touch the process group)
     assert np.array_equal(mus[0], mus[1]) and res[0]["rew"] == res[1]["rew"]
 
 
