@@ -346,6 +346,32 @@ int mbd_sweep_run(mbd_sweep* sweep, const uint32_t* keys, float* mu_0ts_out, flo
 /* average milliseconds of the sweep's rollout launches since the last reset (hipEvents on the launch stream) */
 int mbd_sweep_kernel_time(mbd_sweep* sweep, int enable, float* avg_ms_out, int* count_out);
 
+/* ------------------------------------------------------------------------------------------------ */
+/* in-library exchange — the ONE collective of a sharded diffusion step (the all-gather of the       */
+/* per-candidate mean rewards between mbd_plan_sample_rollout and mbd_plan_score_update,             */
+/* mbd_planner.py:109-111 with N sharded) WITHOUT a collective library: every rank owns a receive     */
+/* window in device memory, peers write their slice into it directly (xGMI peer stores through       */
+/* hipIpc mappings) and raise a flag per rank and epoch; a consumer kernel on the caller's stream    */
+/* waits for the world's flags and hands over the gathered [rows][N] values.  Messages are <= 64 KB: */
+/* the step pays two short kernels instead of a collective launch.  Results are the all-gather's.    */
+/* ------------------------------------------------------------------------------------------------ */
+typedef struct mbd_exchange mbd_exchange;
+#define MBD_IPC_HANDLE_BYTES 64
+#define MBD_EXCHANGE_MAX_RANKS 16
+/* rank `rank` of `world` (<= MBD_EXCHANGE_MAX_RANKS) on `device`: rows x shard floats per rank and step */
+int mbd_exchange_create(int device, int rank, int world, int rows, int shard, mbd_exchange** out);
+int mbd_exchange_destroy(mbd_exchange* x);
+/* this rank's window as an IPC handle (MBD_IPC_HANDLE_BYTES bytes, HOST).  The caller passes the handles around by
+ * any host channel (torch.distributed.all_gather_object, MPI, a file) and hands all of them to _connect. */
+int mbd_exchange_local_handle(mbd_exchange* x, void* handle_out);
+/* handles: [world][MBD_IPC_HANDLE_BYTES] HOST, rank-major (the own entry is not opened) */
+int mbd_exchange_connect(mbd_exchange* x, const void* handles);
+/* d_local [rows][shard] (device) -> every rank's window; *d_all_out: device pointer to [rows][world * shard], rank-major
+ * = candidate order, valid until the next call.  Asynchronous on `stream`; every rank must call it once per step. */
+int mbd_exchange_all_gather(mbd_exchange* x, const float* d_local, const float** d_all_out, void* stream);
+/* MBD_OK, or MBD_ERR_STATE when a wait ran into its time limit (a peer that never arrived); synchronises the device */
+int mbd_exchange_status(mbd_exchange* x);
+
 #ifdef __cplusplus
 }
 #endif

@@ -243,6 +243,49 @@ def shard_bounds(N: int, world: int, rank: int):
     return rank * sh, sh
 
 
+class P2PExchange:
+    """Owner of an ``mbd_exchange`` handle: the step's all-gather as direct peer writes into every rank's receive
+    window (include/mbd_hip.h "in-library exchange") instead of a collective-library call.  The IPC handles of the
+    windows travel once, at construction, through the process group (any backend)."""
+
+    def __init__(self, device: int, rows: int, shard: int, group=None):
+        import torch.distributed as dist
+        self.lib = _capi.load()
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.rows, self.shard = rows, shard
+        h = C.c_void_p()
+        _capi.check(self.lib.mbd_exchange_create(device, self.rank, self.world, rows, shard, C.byref(h)))
+        self.h = h
+        mine = (C.c_ubyte * 64)()
+        _capi.check(self.lib.mbd_exchange_local_handle(self.h, mine))
+        handles = [None] * self.world
+        dist.all_gather_object(handles, bytes(mine), group=group)
+        blob = (C.c_ubyte * (64 * self.world)).from_buffer_copy(b"".join(handles))
+        _capi.check(self.lib.mbd_exchange_connect(self.h, blob))
+        dist.barrier(group)  # every window is mapped everywhere before the first push
+
+    def all_gather(self, local, stream: int) -> int:
+        """local: CUDA tensor [rows, shard].  Returns the device address of the gathered [rows, world * shard] values
+        (valid until the next call); asynchronous on ``stream``."""
+        out = C.c_void_p()
+        _capi.check(self.lib.mbd_exchange_all_gather(self.h, local.data_ptr(), C.byref(out), stream))
+        return out.value
+
+    def status(self):
+        _capi.check(self.lib.mbd_exchange_status(self.h))
+
+    def close(self):
+        if self.h is not None:
+            self.lib.mbd_exchange_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def exchange_rewards(local, world: int, group=None):
     """The ONE exchange step of a diffusion step: every rank contributes the per-candidate values of its
     shard (``local`` [rows, shard]) and receives all N of them, rank-major = candidate order, as
@@ -264,7 +307,7 @@ def exchange_rewards(local, world: int, group=None):
 
 
 def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bool = False, progress=None,
-                        phase_times: dict = None):
+                        phase_times: dict = None, collective: str = None):
     """reverse() (mbd_planner.py:138-148) with the candidates sharded over the ranks of ``group``.
     One all-gather of the per-candidate mean rewards per diffusion step (plus the demo log-densities
     when enabled, packed in the same buffer). Returns (mu_0ts, rew_means) as CUDA tensors.
@@ -272,7 +315,10 @@ def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bo
     ``sync_every_step`` / ``progress``: the reference formats the step's mean reward for its progress bar every
     step (:147), which is a device->host read per step; ``progress(i, rew)`` receives that value.
     ``phase_times``: a dict that receives HIP-event milliseconds per step of phase 1 (sample + rollout), the
-    exchange and phase 2 (score + weighted mean) — each phase is then fenced, for measurement only."""
+    exchange and phase 2 (score + weighted mean) — each phase is then fenced, for measurement only.
+    ``collective``: "torch" (all_gather_into_tensor: RCCL over xGMI, or gloo) or "p2p" (the in-library exchange:
+    peer writes into every rank's window, no collective library on the step's path); default: $MBD_COLLECTIVE or
+    "torch".  Same values either way."""
     import torch
     import torch.distributed as dist
 
@@ -300,6 +346,8 @@ def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bo
     lib = plan.lib
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if phase_times is not None else None
     acc = [0.0, 0.0, 0.0]
+    collective = collective or os.environ.get("MBD_COLLECTIVE", "torch")
+    p2p = P2PExchange(device, rows, sh, group) if (world > 1 and collective == "p2p") else None
     host = HostProgress(plan.Nd - 1, dev) if (sync_every_step or progress is not None) else None
     # Host work that does not depend on the GPU — the key chain (rng, Y0s_rng = split(rng), mbd_planner.py:103) and the
     # declaration of the FOLLOWING step's key (its normals are generated beside this step's rollout) — is done while
@@ -317,13 +365,17 @@ def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bo
         _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, Ybar.data_ptr(), p_loc0, p_loc1, stream))
         if ev:
             ev[1].record()
-        allv = exchange_rewards(local, world, group)
+        if p2p is not None:
+            base = p2p.all_gather(local, stream)
+            p_all0, p_all1 = base, (base + 4 * N if demo else None)
+        else:
+            allv = exchange_rewards(local, world, group)
+            p_all0, p_all1 = allv[0].data_ptr(), (allv[1].data_ptr() if demo else None)
         if ev:
             ev[2].record()
         out = mu[plan.Nd - 1 - i]
         k = plan.Nd - 1 - i
-        _capi.check(lib.mbd_plan_score_update(plan.h, i, ks, Ybar.data_ptr(), allv[0].data_ptr(),
-                                              allv[1].data_ptr() if demo else None, out.data_ptr(),
+        _capi.check(lib.mbd_plan_score_update(plan.h, i, ks, Ybar.data_ptr(), p_all0, p_all1, out.data_ptr(),
                                               host.ptr(k) if host else rew_means[k:].data_ptr(), stream))
         Ybar = out
         if ev:
@@ -346,11 +398,14 @@ def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bo
     if host is not None:
         torch.cuda.synchronize(dev)
         rew_means.copy_(host.t[: plan.Nd - 1])
+    if p2p is not None:
+        p2p.status()  # (raises when a wait ran into its time limit: a peer never arrived)
+        p2p.close()
     return mu.view(plan.Nd - 1, plan.H, plan.Nu), rew_means
 
 
 def run_diffusion(args: Args, device: int = None, return_details: bool = False, progress=None,
-                  force_single: bool = False, measure_phases: bool = False):
+                  force_single: bool = False, measure_phases: bool = False, collective: str = None):
     """mbd_planner.py:38-182. Returns rew_final (float); ``return_details`` adds a dict with mu_0ts,
     per-step mean rewards and the reverse-loop wall time.  ``progress(i, rew)`` is called after every diffusion
     step with the step's mean reward, like the reference's progress bar (:147) — one device->host read per step;
@@ -384,7 +439,8 @@ def run_diffusion(args: Args, device: int = None, return_details: bool = False, 
         torch.cuda.set_device(device)
         torch.cuda.synchronize(device)
         t0 = time.time()
-        mu_t, rm_t = reverse_distributed(plan, rng_exp, device, progress=progress, phase_times=phases)
+        mu_t, rm_t = reverse_distributed(plan, rng_exp, device, progress=progress, phase_times=phases,
+                                         collective=collective)
         torch.cuda.synchronize(device)
         secs = time.time() - t0
         mu, rew_means = mu_t.cpu().numpy(), rm_t.cpu().numpy()

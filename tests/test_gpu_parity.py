@@ -704,7 +704,7 @@ def test_config4_humanoidrun_n4096_eight_shards_every_rank_bitexact(gpu, orc_omp
         p.close()
 
 
-def _run_two_ranks(tmp_path, env_name, N, H, Nd, temp, demo):
+def _run_two_ranks(tmp_path, env_name, N, H, Nd, temp, demo, collective="torch"):
     import json, os, socket, subprocess, sys
     from conftest import ROOT
     with socket.socket() as sk:  # a free rendezvous port
@@ -713,28 +713,32 @@ def _run_two_ranks(tmp_path, env_name, N, H, Nd, temp, demo):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
            "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "dist_worker.py"), str(tmp_path),
            env_name, str(N), str(H), str(Nd), str(temp), str(int(demo))]
-    out = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True,
-                         timeout=900)
+    out = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MBD_COLLECTIVE=collective),
+                         capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-3000:]
     res = [json.load(open(os.path.join(tmp_path, f"rank{r}.json"))) for r in range(2)]
     mus = [np.load(os.path.join(tmp_path, f"mu_rank{r}.npy")) for r in range(2)]
     return res, mus
 
 
-def test_two_real_ranks_run_the_sharded_product_path(gpu, tmp_path):
+@pytest.mark.parametrize("collective", ["torch", "p2p"])
+def test_two_real_ranks_run_the_sharded_product_path(gpu, tmp_path, collective):
     """The product's sharded path with TWO REAL RANKS and real HIP kernels: torch.distributed.run --nproc-per-node 2
     (gloo; both ranks on this box's one GPU) -> run_diffusion -> reverse_distributed (mbd_plan_sample_rollout on
     the rank's shard, the per-step all-gather, mbd_plan_score_update).  Both ranks' mu_0ts, per-step mean rewards
-    and final reward must equal the unsharded plan's bit for bit, and each other's."""
-    res, mus = _run_two_ranks(tmp_path, "humanoidrun", 1024, 50, 12, 0.1, False)
+    and final reward must equal the unsharded plan's bit for bit, and each other's.  collective = "p2p": the step's
+    exchange through the in-library windows (mbd_exchange_*: hipIpc-mapped peer stores + flags; the two processes map
+    each other's window on the one device) instead of the all-gather of the process group."""
+    res, mus = _run_two_ranks(tmp_path, "humanoidrun", 1024, 50, 12, 0.1, False, collective)
     assert all(r["world"] == 2 and r["equal_to_unsharded"] for r in res), res
     assert all(r["force_single_progress_ok"] for r in res), res  # (unsharded plans never touch the process group)
     assert np.array_equal(mus[0], mus[1]) and res[0]["rew"] == res[1]["rew"]
 
 
-def test_two_real_ranks_demo_path(gpu, tmp_path):
+@pytest.mark.parametrize("collective", ["torch", "p2p"])
+def test_two_real_ranks_demo_path(gpu, tmp_path, collective):
     """The same with the demo-conditioned score (config 5's shape): two rows per rank in the one exchange buffer."""
-    res, mus = _run_two_ranks(tmp_path, "humanoidtrack", 256, 50, 8, 0.1, True)
+    res, mus = _run_two_ranks(tmp_path, "humanoidtrack", 256, 50, 8, 0.1, True, collective)
     assert all(r["world"] == 2 and r["equal_to_unsharded"] for r in res), res
     assert np.array_equal(mus[0], mus[1])
 
@@ -1094,3 +1098,23 @@ def test_sweep_rejects_what_it_does_not_batch(gpu):
         Sweep(env, a, 33)  # more than MBD_SWEEP_MAX_PLANS
     with pytest.raises(gpu.MbdError):
         Sweep(get_env("car2d"), Args(env_name="car2d", Nsample=64, Hsample=10, Ndiffuse=4), 2)
+
+
+def test_exchange_single_rank_and_argument_checks(gpu):
+    """mbd_exchange_* with a world of one (no peer to map): the gathered values are the local ones; bad arguments fail."""
+    import torch
+    lib = gpu.load()
+    h = C.c_void_p()
+    gpu.check(lib.mbd_exchange_create(0, 0, 1, 2, 96, C.byref(h)))
+    local = torch.arange(192, dtype=torch.float32, device="cuda").reshape(2, 96).contiguous()
+    out = C.c_void_p()
+    for step in range(5):
+        gpu.check(lib.mbd_exchange_all_gather(h, local.data_ptr(), C.byref(out), torch.cuda.current_stream().cuda_stream))
+        got = torch.empty(192, dtype=torch.float32, device="cuda")
+        C.cdll.LoadLibrary("libamdhip64.so").hipMemcpy(C.c_void_p(got.data_ptr()), out, 768, 3)
+        assert torch.equal(got, local.reshape(-1) )
+        local += 1.0
+    gpu.check(lib.mbd_exchange_status(h))
+    gpu.check(lib.mbd_exchange_destroy(h))
+    assert lib.mbd_exchange_create(0, 3, 2, 1, 8, C.byref(h)) == gpu.MBD_ERR_INVALID
+    assert lib.mbd_exchange_create(0, 0, 99, 1, 8, C.byref(h)) == gpu.MBD_ERR_INVALID
