@@ -19,6 +19,11 @@ step k+1 before it holds step k's mean reward.  `value` is measured with the per
    humanoidrun4096   humanoidrun  N=4096 H=50 temp 0.1   (config 4)
    humanoidtrack2048demo  humanoidtrack N=2048 H=50 temp 0.1 enable_demo (config 5)
    car2d             car2d        N=128  H=30 Ndiffuse=50 (config 1)
+   humanoidrun8192   humanoidrun  N=8192 H=50 temp 0.1   (the reference's own default N for humanoidrun,
+                                                          mbd_planner.py:54-60; the two-candidates-per-lane kernel)
+   sweep8            the reference's 8-seed sweep (mbd/scripts/run_mbd.py:17-39) at the metric's sizes: 8 plans x
+                     N=1024 in lockstep (mbd_sweep_run); a "step" is one diffusion step of all 8 plans and `value`
+                     counts plan-steps/sec
 Ndiffuse=100, seed 0, disable_recommended_params everywhere.
 
 --scaling with G > 1 GPUs (candidates are sharded over ranks, ONE all-gather of the N mean rewards per step):
@@ -43,7 +48,7 @@ for p in (ROOT, os.path.join(ROOT, "model-based-diffusion_amd")):
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TF = 157.3   # MI355X_MICROARCH.md: vector FP32 peak
-ROUND = "r02"
+ROUND = "r03"
 
 CONFIGS = {
     # name: env, N, H, Ndiffuse, temp, demo, lanes per candidate (rollout kernel), kernel label
@@ -58,6 +63,10 @@ CONFIGS = {
     "humanoidtrack2048demo": dict(env="humanoidtrack", N=2048, H=50, Nd=100, temp=0.1, demo=True, lps=16,
                                   kernel="rollout_kernel<16,iso,noslide,3,1,dpp(1,-4,-6)>"),
     "car2d": dict(env="car2d", N=128, H=30, Nd=50, temp=0.1, demo=False, lps=1, kernel="car2d_rollout_kernel"),
+    "humanoidrun8192": dict(env="humanoidrun", N=8192, H=50, Nd=100, temp=0.1, demo=False, lps=16, cpw=8,
+                            static="humanoidrun_pk2", kernel="rollout_pk2_kernel<1,humanoidrun,7> (two candidates per lane)"),
+    "sweep8": dict(env="humanoidrun", N=1024, H=50, Nd=100, temp=0.1, demo=False, lps=16, cpw=8, plans=8,
+                   static="humanoidrun_pk2", kernel="rollout_pk2_kernel<1,humanoidrun,7> over 8 plans x 1024 candidates"),
 }
 
 
@@ -106,7 +115,8 @@ def valu_view(cfg, n_local, kern_ms, n_frames, fsub, fsub_src):
     included)."""
     if kern_ms <= 0 or cfg["lps"] <= 1:
         return None
-    waves = (n_local + 64 // cfg["lps"] - 1) // (64 // cfg["lps"])
+    cpw = cfg.get("cpw", 64 // cfg["lps"])  # candidates per wavefront (8: two per lane)
+    waves = (n_local + cpw - 1) // cpw
     substeps = cfg["H"] * n_frames
     out = {"bound": "fp32-valu-issue", "peak": VALU_PEAK_TF, "unit": "TFLOP/s", "waves": waves,
            "simds_occupied_frac": min(1.0, waves / 1024.0)}
@@ -125,8 +135,68 @@ def valu_view(cfg, n_local, kern_ms, n_frames, fsub, fsub_src):
     return out
 
 
+def reference_baseline(cfg, seconds_budget=25.0):
+    """the REAL reference timed on this box's host cores — tried first, every run.  Needs jax
+    and brax importable and a checkout of the reference ($MBD_REFERENCE_PATH; there is none on the GPU box of this
+    pool, and jax / brax are not in the image: the import fails and the caller falls back to the port).  What is
+    timed: mbd.planners.mbd_planner.run_diffusion (mbd_planner.py:38-182) on JAX's CPU backend at the config's sizes,
+    twice, with Ndiffuse = 2 and Ndiffuse = 2 + K — the difference is K reverse-diffusion steps without the tracing /
+    compilation both runs pay.  Returns (record, None) or (None, reason)."""
+    ref = os.environ.get("MBD_REFERENCE_PATH", "/root/reference")
+    try:
+        os.environ.setdefault("JAX_PLATFORMS", "cpu")
+        import jax
+        import brax
+        if not os.path.isdir(os.path.join(ref, "mbd")):
+            raise ImportError(f"no reference checkout at {ref}")
+        if ref not in sys.path:
+            sys.path.insert(0, ref)
+        from mbd.planners import mbd_planner as ref_planner
+    except Exception as e:  # noqa: BLE001 — ImportError, or whatever a half-installed jax raises
+        return None, f"{type(e).__name__}: {e}"
+
+    def run(nd):
+        a = ref_planner.Args(seed=0, disable_recommended_params=True, not_render=True, env_name=cfg["env"],
+                             Nsample=cfg["N"], Hsample=cfg["H"], Ndiffuse=nd, temp_sample=cfg["temp"],
+                             enable_demo=cfg["demo"])
+        t0 = time.time()
+        with contextlib.redirect_stdout(sys.stderr):
+            ref_planner.run_diffusion(a)
+        return time.time() - t0
+
+    try:
+        t_short = run(2)                      # 1 step + tracing / compilation / reset / final rollout
+        K = 2
+        t_long = run(2 + K)
+        per = max((t_long - t_short) / K, 1e-9)
+        while t_long < seconds_budget / 2 and K < 64:  # a longer sample while it stays inside the budget
+            K *= 2
+            t_long = run(2 + K)
+            per = max((t_long - t_short) / K, 1e-9)
+    except Exception as e:  # noqa: BLE001
+        return None, f"reference run failed: {type(e).__name__}: {e}"
+    return {"value": 1.0 / per, "unit": "diffusion-steps/sec", "cores": os.cpu_count() or 1, "kind": "jax-reference",
+            "versions": {"jax": getattr(jax, "__version__", "?"), "brax": getattr(brax, "__version__", "?")},
+            "sample": f"the reference's run_diffusion on JAX's CPU backend, {cfg['env']} N={cfg['N']} H={cfg['H']}: "
+                      f"(Ndiffuse={2 + K}: {t_long:.1f} s) - (Ndiffuse=2: {t_short:.1f} s) over {K} steps"}, None
+
+
 def cpu_baseline(cfg, seconds_budget=15.0):
-    """The oracle (a port, NOT the JAX reference — jax/brax are absent) timed on the host cores on a
+    """The CPU side of the comparison, on the GPU box's host cores, rank 0 at N=1: the real reference when it can be
+    imported (reference_baseline: kind "jax-reference"), otherwise the oracle (kind "port": a restatement, NOT the JAX
+    reference) on a bounded sample of the same workload — consecutive reverse-diffusion steps of the config.  Also
+    returns the op counter's F_sub for the config's model (the oracle may only be touched from this leg)."""
+    ref_rec, ref_why = reference_baseline(cfg)
+    port, fsub = port_baseline(cfg, seconds_budget)
+    if ref_rec is not None:
+        ref_rec["port"] = {k: port[k] for k in ("value", "cores", "sample")}
+        return ref_rec, fsub
+    port["reference_attempt"] = ref_why
+    return port, fsub
+
+
+def port_baseline(cfg, seconds_budget=15.0):
+    """The oracle (a port, NOT the JAX reference) timed on the host cores on a
     bounded sample of the same workload: consecutive reverse-diffusion steps of the config.  Also returns the
     op counter's F_sub for the config's model (the oracle may only be touched from this leg)."""
     import numpy as np
@@ -182,6 +252,9 @@ def main():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-final-reward", action="store_true")
+    ap.add_argument("--collective", choices=("torch", "p2p", "both"), default="both",
+                    help="N > 1: the step's exchange — torch (all_gather_into_tensor: RCCL over xGMI), p2p (the in-library "
+                         "windows, mbd_exchange_*), both (torch is `value`, p2p is measured after it and reported beside)")
     args = ap.parse_args()
     cfg = CONFIGS[args.config]
     ENV, N_CFG, H, ND, TEMP, DEMO = cfg["env"], cfg["N"], cfg["H"], cfg["Nd"], cfg["temp"], cfg["demo"]
@@ -226,7 +299,33 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     rows = 2 if DEMO else 1
 
-    def measure(N_total, N_local):
+    def measure_sweep():
+        """config sweep8: K lockstep diffusion steps of P plans (mbd_sweep_run with Ndiffuse = K + 1; W + 1 for the
+        warm-up run).  No per-step host read: the reference's sweep prints nothing per step either (not_render runs of
+        run_diffusion keep their progress bar, but the sweep's measure is the time of whole runs)."""
+        from mbd_hip.planners.mbd_planner import Sweep
+        P = cfg["plans"]
+        out = None
+        for nd, timed in ((args.warmup + 1, False), (args.steps + 1, True)):
+            a = Args(seed=0, env_name=ENV, Nsample=N_CFG, Hsample=H, Ndiffuse=max(nd, 2), temp_sample=TEMP,
+                     disable_recommended_params=True, not_render=True)
+            sw = Sweep(env, a, P)
+            keys = []
+            for k in range(P):
+                rng, rng_reset = _capi.prng_split(_capi.prng_key(k), 2)
+                sw.set_state0(k, env.reset(rng_reset))
+                keys.append(_capi.prng_split(rng, 2)[0])
+            sw.kernel_time(enable=timed)
+            torch.cuda.synchronize(dev)
+            _, _, _, secs = sw.run(np.array(keys, np.uint32))
+            torch.cuda.synchronize(dev)
+            if timed:
+                kern_ms, kern_n = sw.kernel_time(enable=False)
+                out = (secs, kern_ms, kern_n)
+            sw.close()
+        return out
+
+    def measure(N_total, N_local, collective="torch"):
         """K synced + K async steps of a plan with N_total candidates of which this rank owns N_local."""
         pargs = Args(seed=0, env_name=ENV, Nsample=N_total, Hsample=H, Ndiffuse=ND, temp_sample=TEMP,
                      enable_demo=DEMO, disable_recommended_params=True, not_render=True)
@@ -247,6 +346,10 @@ def main():
         # step's mean reward into a pinned host slot and the host spins on it (mbd_hip HostProgress)
         host = HostProgress(1, dev)
         st = {"rng": np.asarray(rng_exp, np.uint32), "i": ND - 1, "Ybar": Ybar, "Ynext": Ynext}
+        p2p = None
+        if distributed and collective == "p2p":
+            from mbd_hip.planners.mbd_planner import P2PExchange
+            p2p = P2PExchange(local_rank, rows, N_local)
 
         p_loc0, p_loc1 = local[0].data_ptr(), (local[1].data_ptr() if DEMO else None)
         p_rewmean = rew_mean.data_ptr()
@@ -271,7 +374,10 @@ def main():
         def step(read_back):
             i, ks, pY, pYn = st["i"], st["ks"], st["pY"], st["pYn"]
             _capi.check(lib.mbd_plan_sample_rollout(plan.h, i, ks, pY, p_loc0, p_loc1, stream))
-            if distributed and backend == "nccl":
+            if p2p is not None:  # the in-library exchange: peer stores into every rank's window + flags
+                base = p2p.all_gather(local, stream)
+                p_s0, p_s1 = base, (base + 4 * N_total if DEMO else None)
+            elif distributed and backend == "nccl":
                 dist.all_gather_into_tensor(gath, local)  # the ONE collective of a diffusion step (RCCL/xGMI)
                 src = gath.view(world, rows, N_local).permute(1, 0, 2).reshape(rows, N_total) if rows > 1 else \
                     gath.view(1, N_total)
@@ -328,6 +434,9 @@ def main():
 
         sync = timed(True)
         asyn = timed(False)
+        if p2p is not None:
+            p2p.status()
+            p2p.close()
         plan.close()
         return sync, asyn
 
@@ -335,21 +444,63 @@ def main():
     runs = {"strong": (strong_local * world, strong_local)}
     if world > 1:
         runs["weak"] = (N_CFG * world, N_CFG)
-    res = {k: measure(*v) for k, v in runs.items() if k == args.scaling or world > 1}
+    is_sweep = "plans" in cfg
+    if is_sweep:
+        assert world == 1, "config sweep8 is a single-GPU workload (the plans of a sweep are independent: run one per GPU)"
+        sw = measure_sweep()
+        res = {"strong": (sw, sw)}
+    else:
+        main_coll = "p2p" if args.collective == "p2p" else "torch"
+        res = {k: measure(*v, collective=main_coll) for k, v in runs.items() if k == args.scaling or world > 1}
     if args.scaling not in res:  # one GPU, --scaling weak: the same measurement
         res[args.scaling] = res["strong"]
+    # the other collective, after the headline measurement and guarded: a failure here (a peer that cannot map a
+    # window, a wait that runs into its limit) is reported, it never costs the line its `value`
+    other_coll = None
+    if distributed and world > 1 and args.collective == "both" and not is_sweep:
+        try:
+            oc = measure(*runs[args.scaling], collective="p2p")
+            other_coll = {"collective": "p2p (mbd_exchange_*: hipIpc-mapped windows, peer stores + epoch flags)",
+                          "elapsed": oc[0][0], "elapsed_async": oc[1][0], "kernel_avg_ms": oc[1][1]}
+        except Exception as e:  # noqa: BLE001
+            other_coll = {"collective": "p2p", "error": f"{type(e).__name__}: {e}"}
+        ok = torch.tensor([0 if "error" in other_coll else 1], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if int(ok.item()) == 0 and "error" not in other_coll:
+            other_coll = {"collective": "p2p", "error": "failed on another rank"}
+
+    # where a sharded step's time goes: HIP events around phase 1 (sample + rollout), the exchange and phase 2 (score +
+    # weighted mean) of a whole plan, each phase fenced (measurement only; run_diffusion(measure_phases=True))
+    phase_ms = None
+    if distributed and not is_sweep:
+        a = Args(seed=0, env_name=ENV, Nsample=runs[args.scaling][0], Hsample=H, Ndiffuse=min(ND, 30), temp_sample=TEMP,
+                 enable_demo=DEMO, disable_recommended_params=True, not_render=True)
+        with contextlib.redirect_stdout(sys.stderr):
+            _, det = run_diffusion(a, device=local_rank, return_details=True, measure_phases=True,
+                                   collective="torch" if args.collective != "p2p" else "p2p")
+        phase_ms = det["phase_ms"]
 
     final = None
-    if rank == 0 and not args.no_final_reward and not distributed:
-        # the metric's second half: final reward of complete plans, seeds 0..7 as mbd/scripts/run_mbd.py:20
-        rews = []
+    if not args.no_final_reward and (rank == 0 or distributed):
+        # the metric's second half: final reward of complete plans, seeds 0..7 as mbd/scripts/run_mbd.py:20.  With
+        # G > 1 ranks every plan runs SHARDED over the ranks (the product's multi-GPU path: run_diffusion ->
+        # reverse_distributed) and, on rank 0, once more on one GPU: the two must agree bit for bit (variant B: every
+        # rank re-derives the softmax and the weighted mean over all N from identical inputs)
+        rews, single = [], []
+        n_final = N_CFG if not distributed else runs[args.scaling][0]
         for seed in range(8):
-            a = Args(seed=seed, env_name=ENV, Nsample=N_CFG, Hsample=H, Ndiffuse=ND, temp_sample=TEMP,
+            a = Args(seed=seed, env_name=ENV, Nsample=n_final, Hsample=H, Ndiffuse=ND, temp_sample=TEMP,
                      enable_demo=DEMO, disable_recommended_params=True, not_render=True)
             with contextlib.redirect_stdout(sys.stderr):  # the reference prints "init sigma = ..." (:92); stdout
-                rews.append(float(run_diffusion(a, device=local_rank)))  # carries the one JSON line only
+                rews.append(float(run_diffusion(Args(**vars(a)), device=local_rank)))  # carries the one JSON line only
+                if distributed and rank == 0:
+                    single.append(float(run_diffusion(Args(**vars(a)), device=local_rank, force_single=True)))
         final = {"seeds": list(range(8)), "rew_final": rews, "mean": float(np.mean(rews)),
-                 "std": float(np.std(rews))}
+                 "std": float(np.std(rews)), "N": n_final}
+        if distributed and rank == 0:
+            final["sharded_over"] = world
+            final["equals_one_gpu_bitwise"] = bool(np.array_equal(np.float32(rews), np.float32(single)))
+            final["rew_final_one_gpu"] = single
 
     if rank == 0:
         def rate(mode, which):
@@ -379,8 +530,11 @@ def main():
                                    f"temp={TEMP}{' enable_demo' if DEMO else ''} seed=0 disable_recommended_params",
                        "name": args.config, "N_total": N_total, "N_per_gpu": N_local, "H": H, "Nu": Nu,
                        "n_frames": n_frames,
-                       "collective": "all_gather(rews) per step (variant B: every rank re-derives the softmax and the "
-                                     "weighted mean over all N from identical inputs)" if distributed else "none"},
+                       "collective": (("all_gather(rews) per step through " +
+                                       ("torch.distributed (RCCL over xGMI)" if args.collective != "p2p" else
+                                        "the in-library windows (mbd_exchange_*)") +
+                                       " (variant B: every rank re-derives the softmax and the weighted mean over all N "
+                                       "from identical inputs)") if distributed else "none")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": cfg["kernel"], "kernel_avg_ms": kern_ms,
@@ -391,6 +545,28 @@ def main():
                                  "dependent FP32 VALU issue, not HBM (DESIGN.md §Roofline)"},
             "final_reward": final,
         }
+        if is_sweep:  # plan-steps: K lockstep steps of P plans
+            P = cfg["plans"]
+            out["value"] = out["value_async"] = P * args.steps / el_a
+            out["ms_per_step"] = out["ms_per_step_async"] = 1e3 * el_a / args.steps
+            out["unit"] = f"plan-steps/sec: diffusion steps of the {P} plans of a seed sweep advanced in lockstep (mbd_sweep_run)"
+            out["config"]["workload"] = (f"sweep8: {P} plans x {ENV} N={N_CFG} H={H} temp={TEMP}, seeds 0..{P - 1}, one rollout "
+                                         f"launch over {P * N_CFG} candidates + one score launch per step")
+            out["config"]["plans"] = P
+            bal = P * b_alg_bytes(N_CFG, H, Nu, DEMO)
+            out["roofline"].update(achieved=(bal / 1e9) / (kern_ms / 1e3) if kern_ms > 0 else 0.0,
+                                   algorithmic_bytes_per_launch=bal)
+            out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
+            out["roofline"]["traffic"] = None
+        if phase_ms is not None:
+            out["phase_ms"] = phase_ms
+        if other_coll is not None:
+            if "elapsed" in other_coll:
+                nt = runs[mode][0]
+                fac = (nt / N_CFG if mode == "weak" else 1.0)
+                other_coll["value"] = args.steps / other_coll.pop("elapsed") * fac
+                other_coll["value_async"] = args.steps / other_coll.pop("elapsed_async") * fac
+            out["other_collective"] = other_coll
         if world > 1:
             other = "weak" if mode == "strong" else "strong"
             ov, oms = rate(other, "sync")
@@ -402,7 +578,7 @@ def main():
             out["cpu_baseline"], live = cpu_baseline(cfg)
             if live:
                 fsub, fsub_src = live, "oracle/count_ops.cc (this run)"
-        out["valu"] = valu_view(cfg, N_local, kern_ms, n_frames, fsub, fsub_src)
+        out["valu"] = valu_view(cfg, N_local * cfg.get("plans", 1), kern_ms, n_frames, fsub, fsub_src)
         print(json.dumps(out))
     if distributed:
         dist.barrier()

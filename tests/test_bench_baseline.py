@@ -1,0 +1,79 @@
+"""bench.py's CPU-baseline leg tries the REAL reference first (jax + brax + a checkout of the
+reference) and falls back to the port.  Neither jax nor brax exists in this image, so the reference branch is
+exercised with stub modules that have the reference's call surface (mbd.planners.mbd_planner.Args / run_diffusion)."""
+import importlib
+import os
+import sys
+import textwrap
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture()
+def bench_mod():
+    sys.path.insert(0, ROOT)
+    try:
+        yield importlib.import_module("bench")
+    finally:
+        sys.path.remove(ROOT)
+
+
+def test_falls_back_to_the_port_when_the_reference_cannot_be_imported(bench_mod, monkeypatch):
+    monkeypatch.setenv("MBD_REFERENCE_PATH", "/nonexistent")
+    rec, why = bench_mod.reference_baseline(bench_mod.CONFIGS["car2d"])
+    assert rec is None and ("ModuleNotFoundError" in why or "ImportError" in why)
+    port, _ = bench_mod.cpu_baseline(bench_mod.CONFIGS["car2d"], seconds_budget=0.5)
+    assert port["kind"] == "port" and port["value"] > 0 and "reference_attempt" in port
+
+
+def test_reference_branch_with_stub_modules(bench_mod, tmp_path, monkeypatch):
+    stubs = tmp_path / "stubs"
+    ref = tmp_path / "ref"
+    for d in (stubs / "jax", stubs / "brax", ref / "mbd" / "planners"):
+        d.mkdir(parents=True)
+    (stubs / "jax" / "__init__.py").write_text("__version__ = '0.0-stub'\n")
+    (stubs / "brax" / "__init__.py").write_text("__version__ = '0.0-stub'\n")
+    (ref / "mbd" / "__init__.py").write_text("")
+    (ref / "mbd" / "planners" / "__init__.py").write_text("")
+    (ref / "mbd" / "planners" / "mbd_planner.py").write_text(textwrap.dedent('''
+        import time
+        from dataclasses import dataclass
+        CALLS = []
+        @dataclass
+        class Args:
+            seed: int = 0
+            disable_recommended_params: bool = False
+            not_render: bool = False
+            env_name: str = "ant"
+            Nsample: int = 2048
+            Hsample: int = 50
+            Ndiffuse: int = 100
+            temp_sample: float = 0.1
+            beta0: float = 1e-4
+            betaT: float = 1e-2
+            enable_demo: bool = False
+        def run_diffusion(args):
+            CALLS.append(args)
+            time.sleep(0.05 + 0.01 * (args.Ndiffuse - 1))   # "compilation" + 10 ms per diffusion step
+            print("init sigma = stub")                        # (the reference prints to stdout: must not reach ours)
+            return 1.0
+    '''))
+    monkeypatch.syspath_prepend(str(stubs))
+    monkeypatch.setenv("MBD_REFERENCE_PATH", str(ref))
+    for m in ("jax", "brax", "mbd", "mbd.planners", "mbd.planners.mbd_planner"):
+        monkeypatch.delitem(sys.modules, m, raising=False)
+    try:
+        rec, why = bench_mod.reference_baseline(bench_mod.CONFIGS["metric"], seconds_budget=0.6)
+        assert why is None and rec["kind"] == "jax-reference" and rec["versions"] == {"jax": "0.0-stub", "brax": "0.0-stub"}
+        assert 50 < rec["value"] < 200, rec  # 10 ms per step -> ~100 steps/s, the fixed 50 ms cancelled out
+        calls = sys.modules["mbd.planners.mbd_planner"].CALLS
+        assert all(c.env_name == "humanoidrun" and c.Nsample == 1024 and c.Hsample == 50 and c.disable_recommended_params
+                   and c.not_render for c in calls)
+        assert calls[0].Ndiffuse == 2 and calls[-1].Ndiffuse > 2
+    finally:
+        for m in ("jax", "brax", "mbd", "mbd.planners", "mbd.planners.mbd_planner"):
+            sys.modules.pop(m, None)
+        if str(ref) in sys.path:
+            sys.path.remove(str(ref))

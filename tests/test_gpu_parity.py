@@ -639,6 +639,33 @@ def test_bench_multirank_code_path_on_rccl_with_one_rank(gpu):
     assert d["n_gpus"] == 1 and d["config"]["collective"].startswith("all_gather") and d["value"] > 300.0
 
 
+def test_bench_two_ranks_line_is_complete(gpu):
+    """bench.py --gpus 2 the way the driver launches it, as a dry run on this box's ONE GPU (MBD_DIST_BACKEND=gloo, both
+    ranks on device 0): the line must carry the final reward of the SHARDED plans and say that it equals the one-GPU
+    values bit for bit, the per-phase times of a sharded step, and the second collective (the in-library windows)
+    measured beside the process group's all-gather."""
+    import json, os, socket, subprocess, sys
+    from conftest import ROOT
+    env = dict(os.environ, MBD_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "10",
+           "--warmup", "2", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["N_per_gpu"] == 512
+    fr = d["final_reward"]
+    assert fr["sharded_over"] == 2 and fr["equals_one_gpu_bitwise"] is True and len(fr["rew_final"]) == 8
+    assert set(d["phase_ms"]) >= {"phase1_ms", "exchange_ms", "phase2_ms"} and d["phase_ms"]["phase1_ms"] > 0.3
+    assert d["other_collective"]["collective"].startswith("p2p") and d["other_collective"]["value"] > 100.0, d["other_collective"]
+    assert d["other_scaling"]["scaling"] == "weak" and d["other_scaling"]["N_per_gpu"] == 1024
+
+
 # ---- BASELINE.json configs 3 / 4 / 5 at their full sizes (round-2 verdict item 1) --------------------------------
 def test_config3_halfcheetah_full_size_step_bitexact(gpu, orc_omp):
     """BASELINE config 3 at FULL size: halfcheetah, N=1024, H=50, temp 0.4 — a whole reverse-diffusion step
