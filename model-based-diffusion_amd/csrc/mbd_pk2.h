@@ -440,7 +440,7 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
         const v3x2 icd = scale2s(cdv, ic_ib);
         const f2 wn = splat(ic_inv_mass) + fma2(cnx, icnx, cny * icny), wt = splat(ic_inv_mass) + dot2(cdv, icd);
         const f2 rest = splat(-elast) * vn_prev;
-        const f2 dvn = fmin2(rest, splat(0.0f)) - vn;
+        const f2 dvn = fmaxs2(rest, 0.0f) - vn;
         const f2 jt_max = (splat(mu) * con_dlam[j]) * splat(inv_dt);
         const f2 dvt = fmin2(jt_max * wt, vtn);
         const f2 jn = div2_(dvn, wn), jt = -div2_pos_(dvt, wt);

@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
           const float wn = ffma(icn, rcx, im_c);
           const float wt = ffma(rcz, rcz * iy_c, im_c);
           const float rest = -elast * vn_prev;
-          const float dvn = fmin_(rest, 0.0f) - vptz;
+          const float dvn = fmax_(rest, 0.0f) - vptz;
           const float jt_max = (mu * cdlam[j]) * inv_dt;
           const float dvt = fmin_(jt_max * wt, vtn);
           const f2 q_nt = div2_sp_(mk2(dvn, dvt), mk2(wn, wt));

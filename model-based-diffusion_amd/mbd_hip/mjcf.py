@@ -361,6 +361,12 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
     friction = floor["friction"] if floor else 1.0
     iso = True
     nq = nqd = 0
+    # <compiler settotalmass="M">: MuJoCo rescales every body's mass and inertia so that the model weighs M (the stock
+    # half_cheetah.xml: settotalmass="14")
+    settotal = float(comp.get("settotalmass", "-1")) if comp is not None else -1.0
+    mscale = 1.0
+    if settotal > 0:
+        mscale = settotal / sum(g.mass_inertia()[0] for ent in links for g in ent["body"].geoms)
     for l, ent in enumerate(links):
         b: _Body = ent["body"]
         F["parent"][l] = ent["parent"]
@@ -370,7 +376,7 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
         ms, cs, Is = [], [], []
         for g in b.geoms:
             m_g, I_g = g.mass_inertia()
-            ms.append(m_g); cs.append(g.pos); Is.append(I_g)
+            ms.append(m_g * mscale); cs.append(g.pos); Is.append(I_g * mscale)
         mass = float(sum(ms))
         com = sum(m_g * c for m_g, c in zip(ms, cs)) / mass
         I = np.zeros((3, 3))

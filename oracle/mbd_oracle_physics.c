@@ -525,7 +525,11 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     cross_bz0(rc, dir, cdv); iinv_apply(&in[l], cdv, icd);
     real wn = in[l].inv_mass + dot_az0(cn, icn), wt = in[l].inv_mass + sp_dot3(cdv, icd);
     real rest = -R(m->elasticity) * vn_prev;
-    real dvn = sp_min(rest, R(0)) - vn;
+    /* restitution (Mueller et al. 2020, eq. 34, written for a normal that points OUT of the floor, +z): an approaching
+     * contact has vn_prev < 0, and the velocity after the solve is max(-e vn_prev, 0).  (Until round 3 this read
+     * min(...): with this normal that term is never positive and the elasticity did nothing — found by
+     * tests/test_oracle_invariants.py::test_restitution; every built-in model has e = 0, for which both forms give 0.) */
+    real dvn = sp_max(rest, R(0)) - vn;
     real jt_max = (mu * con[k].dlam) * inv_dt; /* friction impulse bound mu * lambda_n / h */
     real dvt = sp_min(jt_max * wt, vtn);
     real jn = sp_div(dvn, wn), jt = -sp_div_pos(dvt, wt);

@@ -315,7 +315,7 @@ static void substep_planar(const mbd_model_t* m, pxf_t* x, pmo_t* xd, const real
     const real wn = sp_fma(icn, rcx, K[l].im);
     const real wt = sp_fma(rcz, rcz * K[l].iy, K[l].im);
     const real rest = -R(m->elasticity) * vn_prev;
-    const real dvn = sp_min(rest, R(0)) - vptz;
+    const real dvn = sp_max(rest, R(0)) - vptz;
     const real jt_max = (mu * cdlam[k]) * inv_dt;
     const real dvt = sp_min(jt_max * wt, vtn);
     const real jn = sp_div(dvn, wn);
