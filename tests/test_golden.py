@@ -90,6 +90,9 @@ def _synthetic_stage_file(orc, path, name, corrupt=None):
         put(f"stage_{stn}", stages[k])
     rec["stage_1_acceleration_xdd_vel"] = stages[0][:, 7:10] + np.asarray(m.fields["gravity"], np.float32)
     rec["stage_1_acceleration_xdd_ang"] = stages[0][:, 10:13].copy()
+    # the second record of the schema: the substep from a settled state, keys prefixed "contact_"
+    for k in [k for k in rec if not k.startswith("sys_")]:
+        rec["contact_" + k] = np.array(rec[k], copy=True)
     if corrupt:
         stage, link, key, delta = corrupt
         rec[f"stage_{stage}_{key}"][link, 0] += delta
@@ -113,3 +116,13 @@ def test_compare_golden_localises_a_mismatch(orc, tmp_path, name):
     lines, first = compare_golden.compare(bad, 1e-5)
     assert first is not None and first[0] == "3_joint_position" and first[1] == 2 and first[2] == "pos", lines
     assert any("FIRST MISMATCH" in l and "3_joint_position" in l for l in lines)
+    # ... and one planted in the settled-state record only (stage 6: the friction bound's stage) is named as such
+    bad2 = str(tmp_path / "bad2" / f"golden_{name}_N1_H1.npz")
+    os.makedirs(os.path.dirname(bad2))
+    _synthetic_stage_file(orc, bad2, name, corrupt=("6_contact_velocity", 1, "xd_vel", 2e-3))
+    g = dict(np.load(bad2))
+    g["stage_6_contact_velocity_xd_vel"], g["contact_stage_6_contact_velocity_xd_vel"] = \
+        g["contact_stage_6_contact_velocity_xd_vel"], g["stage_6_contact_velocity_xd_vel"]
+    np.savez(bad2, **g)
+    lines, first = compare_golden.compare(bad2, 1e-5)
+    assert first is not None and first[0] == "contact:6_contact_velocity" and first[1] == 1, lines

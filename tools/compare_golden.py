@@ -69,21 +69,43 @@ def compare(path, tol=1e-5):
     orc_mod.build()
     orc = orc_mod.Oracle("f32")
     orc.lib.orc_substep_stages.argtypes = [C.c_void_p] + [np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")] * 4
-    s_in = _state(g, "substep_in")[:L]
-    act = np.ascontiguousarray(g["substep_action"], np.float32)
+    for prefix in ("", "contact_"):  # the substep from state_init, then the one from a settled state (contacts active)
+        if f"{prefix}substep_in_x_pos" not in g:
+            continue
+        if prefix:
+            n_touch = int((np.asarray(g[f"{prefix}stage_4_contact_position_contact_dist"]) < 0).sum()) \
+                if f"{prefix}stage_4_contact_position_contact_dist" in g else -1
+            lines.append(f"---- substep from the settled state ({n_touch if n_touch >= 0 else '?'} penetrating contacts)")
+        first = _compare_substep(g, prefix, m, ms, L, orc, tol, lines, first)
+    if first is not None:
+        st = first[0]
+        lines.append(f"FIRST MISMATCH: stage {st}, link {first[1]} ({m.link_names[first[1]] if 0 <= first[1] < L else '?'}), "
+                     f"{first[2]}: err {first[3]:.3g} > {tol:g}")
+        lines.append(f"  suspects: {SUSPECTS.get(st.replace('contact:', ''), 'see the stage-by-stage lines above')}")
+    else:
+        lines.append(f"all stages within {tol:g}")
+    return lines, first
+
+
+def _compare_substep(g, prefix, m, ms, L, orc, tol, lines, first):
+    import ctypes as C
+    tag = "contact:" if prefix else ""
+    P = prefix
+    s_in = _state(g, f"{P}substep_in")[:L]
+    act = np.ascontiguousarray(g[f"{P}substep_action"], np.float32)
     out = np.zeros((L, 13), np.float32)
     stages = np.zeros((6, L, 13), np.float32)
     orc.lib.orc_substep_stages(C.addressof(ms), np.ascontiguousarray(s_in).reshape(-1), act, out.reshape(-1), stages.reshape(-1))
-    staged = bool(g["stage_composition_matches_pipeline_step"]) if "stage_composition_matches_pipeline_step" in g else False
+    staged = bool(g[f"{P}stage_composition_matches_pipeline_step"]) if f"{P}stage_composition_matches_pipeline_step" in g else False
     cols = {"pos": slice(0, 3), "rot": slice(3, 7), "vel": slice(7, 10), "ang": slice(10, 13)}
     if staged:
         for k, st in enumerate(STAGES):
             if st == "1_acceleration":  # accelerations (gravity excluded here, included there): compare them minus gravity
-                ref_v = np.asarray(g[f"stage_{st}_xdd_vel"], np.float32)[:L] - np.asarray(m.fields["gravity"], np.float32)
-                ref_w = np.asarray(g[f"stage_{st}_xdd_ang"], np.float32)[:L]
+                ref_v = np.asarray(g[f"{P}stage_{st}_xdd_vel"], np.float32)[:L] - np.asarray(m.fields["gravity"], np.float32)
+                ref_w = np.asarray(g[f"{P}stage_{st}_xdd_ang"], np.float32)[:L]
                 pairs = {"lin. accel": (stages[k][:, 7:10], ref_v), "ang. accel": (stages[k][:, 10:13], ref_w)}
             else:
-                ref = _state(g, f"stage_{st}")[:L]
+                ref = _state(g, f"{P}stage_{st}")[:L]
                 pairs = {q: (stages[k][:, c], ref[:, c]) for q, c in cols.items()}
                 # q and -q are the same rotation
                 a, b = pairs["rot"]
@@ -93,10 +115,10 @@ def compare(path, tol=1e-5):
                 e = np.abs(a - b).max(axis=1) / np.maximum(1.0, np.abs(b).max(axis=1))
                 lines.append(f"stage {st:20s} {q:10s} max err {e.max():.3g} (link {int(e.argmax())})")
                 if e.max() > tol and first is None:
-                    first = (st, int(e.argmax()), q, float(e.max()))
+                    first = (tag + st, int(e.argmax()), q, float(e.max()))
     else:
         lines.append("stage records absent or flagged (this Brax composes its step differently): end-of-substep only")
-    ref = _state(g, "substep_out")[:L]
+    ref = _state(g, f"{P}substep_out")[:L]
     for q, c in cols.items():
         a, b = out[:, c], ref[:, c]
         if q == "rot":
@@ -105,15 +127,8 @@ def compare(path, tol=1e-5):
         e = np.abs(a - b).max(axis=1) / np.maximum(1.0, np.abs(b).max(axis=1))
         lines.append(f"end of substep        {q:10s} max err {e.max():.3g} (link {int(e.argmax())})")
         if e.max() > tol and first is None:
-            first = ("end_of_substep", int(e.argmax()), q, float(e.max()))
-    if first is not None:
-        st = first[0]
-        lines.append(f"FIRST MISMATCH: stage {st}, link {first[1]} ({m.link_names[first[1]] if 0 <= first[1] < L else '?'}), "
-                     f"{first[2]}: err {first[3]:.3g} > {tol:g}")
-        lines.append(f"  suspects: {SUSPECTS.get(st, 'see the stage-by-stage lines above')}")
-    else:
-        lines.append(f"all stages within {tol:g}")
-    return lines, first
+            first = (tag + "end_of_substep", int(e.argmax()), q, float(e.max()))
+    return first
 
 
 if __name__ == "__main__":

@@ -27,10 +27,13 @@ def _np(tree):
     return jax.tree_util.tree_map(lambda a: np.asarray(a), tree)
 
 
-def dump_substep_stages(env, state_init, action, out):
+def dump_substep_stages(env, state_init, action, out, prefix=""):
     """(B): re-composes brax/positional/pipeline.py::step from Brax's OWN stage functions, records x_i / xd_i after
     each, and checks the composition against pipeline.step itself — if the installed Brax composes its step
-    differently the stage records are dropped (with a note) and only the end-of-substep state is kept."""
+    differently the stage records are dropped (with a note) and only the end-of-substep state is kept.
+    `prefix`: "" for the substep from state_init (usually in the air: stages 4 and 6 do nothing), "contact_" for the
+    substep from a settled state (feet on the floor; links with two colliders have both in contact) — the record that
+    decides DESIGN.md §9's guesses about friction bounds and several contacts on one link."""
     import jax
     from jax import numpy as jnp
     from brax import actuator, com, kinematics  # noqa: F401
@@ -77,7 +80,12 @@ def dump_substep_stages(env, state_init, action, out):
             p_i, dlambda = call(collisions.resolve_position, (sys_, x_i, x_i_prev, contact),
                                 (sys_, st.replace(x_i=x_i), x_i_prev, contact))
             x_i = tadd(x_i, p_i)
-            put("4_contact_position", x_i, xd_i, dict(dlambda=dlambda) if dlambda is not None else None)
+            extra4 = dict(dlambda=dlambda) if dlambda is not None else {}
+            if contact is not None:  # which links touch, and how deep: how many contacts act on ONE link
+                for k_, name_ in (("dist", "contact_dist"), ("link_idx", "contact_link_idx")):
+                    if hasattr(contact, k_):
+                        extra4[name_] = np.asarray(getattr(contact, k_))
+            put("4_contact_position", x_i, xd_i, extra4 or None)
             xd_i_prev = xd_i
             xd_i = integrator.project_xd(sys_, x_i, x_i_prev)
             put("5_project", x_i, xd_i)
@@ -121,7 +129,8 @@ def dump_substep_stages(env, state_init, action, out):
     for name in ("stiffness", "damping", "limit"):
         if hasattr(sys_.dof, name):
             rec[f"sys_dof_{name}"] = np.asarray(getattr(sys_.dof, name))
-    out.update(rec)
+    # (the compiled system is recorded once, with the unprefixed substep)
+    out.update({(k if k.startswith("sys_") else prefix + k): v for k, v in rec.items() if not (prefix and k.startswith("sys_"))})
 
 
 def main():
@@ -153,6 +162,12 @@ def main():
                x0_pos=np.asarray(state_init.pipeline_state.x.pos), x0_rot=np.asarray(state_init.pipeline_state.x.rot))
     if hasattr(env, "sys"):  # (B) one substep, stage by stage; fixed action 0.3 on every actuator
         dump_substep_stages(env, state_init, jnp.full((Nu,), 0.3), out)
+        # (B') the same from a SETTLED state — 12 control steps under that action: the feet are on the floor, links with
+        # two colliders (hopper / walker2d / halfcheetah feet, ant legs) have both in contact
+        st = state_init
+        for _ in range(12):
+            st = step_env(st, jnp.full((Nu,), 0.3))
+        dump_substep_stages(env, st, jnp.full((Nu,), 0.3), out, prefix="contact_")
     Ybar = jnp.zeros([H, Nu])
     r = rng_exp
     for k, i in enumerate(range(Nd - 1, Nd - 1 - steps, -1)):
