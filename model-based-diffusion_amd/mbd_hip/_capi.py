@@ -121,6 +121,27 @@ def load() -> C.CDLL:
     return lib
 
 
+LEVERS = ("MBD_NO_DPP", "MBD_NO_NFR_CONST", "MBD_NO_REWARD_CONST", "MBD_NO_PLANAR_FLAGS", "MBD_NO_FAST_SLIDES",
+          "MBD_NO_FUSED_NOISE", "MBD_NO_LAZY", "MBD_NO_PREFETCH", "MBD_NO_AUX", "MBD_WMEAN_SPLIT", "MBD_NO_FUSED_SCORE",
+          "MBD_PK2", "MBD_WPB", "MBD_LDS_RESERVE")
+
+
+def debug_set(name: str, value: int) -> None:
+    """include/mbd_hip_debug.h: a test / A-B lever of the library (-1: not set).  The library reads the environment
+    variables of the same names once, when it is first used; afterwards only this call changes a lever."""
+    lib = load()
+    lib.mbd_debug_set.argtypes = [C.c_char_p, _i]
+    check(lib.mbd_debug_set(name.encode(), int(value)))
+
+
+def debug_get(name: str) -> int:
+    lib = load()
+    lib.mbd_debug_get.argtypes = [C.c_char_p, C.POINTER(_i)]
+    v = _i(0)
+    check(lib.mbd_debug_get(name.encode(), C.byref(v)))
+    return v.value
+
+
 def check(rc: int) -> None:
     if rc != MBD_OK:
         raise MbdError(rc, load().mbd_last_error().decode())

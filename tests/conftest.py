@@ -48,3 +48,20 @@ def load_model(name):
     path = os.path.join(ROOT, "model-based-diffusion_amd", "assets", "compiled", f"{name}.json")
     with open(path) as f:
         return Model.from_json(f.read())
+
+
+@pytest.fixture()
+def levers(lib):
+    """Set test levers of the library for one test (include/mbd_hip_debug.h): levers(MBD_PK2=1, MBD_NO_DPP=1); -1 =
+    not set.  Restored afterwards.  (The library reads the environment once; afterwards only mbd_debug_set counts.)"""
+    from mbd_hip import _capi
+    saved = {}
+
+    def set_(**kw):
+        for k, v in kw.items():
+            if k not in saved:
+                saved[k] = _capi.debug_get(k)
+            _capi.debug_set(k, int(v))
+    yield set_
+    for k, v in saved.items():
+        _capi.debug_set(k, v)

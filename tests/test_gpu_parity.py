@@ -97,10 +97,10 @@ def test_rollout_bitexact(gpu, orc, name, B, H, sigma):
 @pytest.mark.parametrize("name,B,H,sigma", [("humanoidrun", 40, 50, 0.6), ("humanoidstandup", 20, 30, 0.5),
                                             ("hopper", 48, 50, 0.5), ("halfcheetah", 24, 50, 0.5),
                                             ("walker2d", 24, 30, 0.5), ("ant", 20, 50, 0.5), ("cartpole", 64, 50, 0.8)])
-def test_rollout_bitexact_shuffle_fallback(gpu, orc, name, B, H, sigma, monkeypatch):
+def test_rollout_bitexact_shuffle_fallback(gpu, orc, name, B, H, sigma, monkeypatch, levers):
     """Every built-in tree fits a DPP family, so the ds_bpermute exchange — the path an arbitrary MJCF tree
     takes — is forced with MBD_NO_DPP=1 (read when the env is created) and held to the same bit-exact bar."""
-    monkeypatch.setenv("MBD_NO_DPP", "1")
+    levers(MBD_NO_DPP=1)
     _rollout_bitexact(gpu, orc, name, B, H, sigma)
 
 
@@ -108,15 +108,15 @@ def test_rollout_bitexact_shuffle_fallback(gpu, orc, name, B, H, sigma, monkeypa
                                             ("humanoidstandup", 12, 20, 0.5), ("hopper", 48, 50, 0.5),
                                             ("halfcheetah", 24, 50, 0.5), ("walker2d", 24, 30, 0.5),
                                             ("cartpole", 64, 50, 0.8)])
-def test_rollout_bitexact_general_instantiations(gpu, orc, name, B, H, sigma, monkeypatch):
+def test_rollout_bitexact_general_instantiations(gpu, orc, name, B, H, sigma, monkeypatch, levers):
     """The built-in models run instantiations with their switches, reward kind and n_frames as compile-time constants;
     a model that differs in any of them (another MJCF, another n_frames) runs the general instantiation of the same
     kernel.  Forced here for the built-in models (switches read per launch) and held to the same bar."""
     for k in ("MBD_NO_PLANAR_FLAGS", "MBD_NO_REWARD_CONST", "MBD_NO_NFR_CONST"):
-        monkeypatch.setenv(k, "1")
+        levers(**{k: 1})
     _rollout_bitexact(gpu, orc, name, B, H, sigma)
-    monkeypatch.delenv("MBD_NO_PLANAR_FLAGS")  # (n_frames at run time under the compile-time switches)
-    monkeypatch.delenv("MBD_NO_REWARD_CONST")
+    levers(MBD_NO_PLANAR_FLAGS=-1)  # (n_frames at run time under the compile-time switches)
+    levers(MBD_NO_REWARD_CONST=-1)
     _rollout_bitexact(gpu, orc, name, B, H, sigma)
 
 
@@ -142,7 +142,7 @@ def test_rollout_bitexact_other_n_frames(gpu, orc, name, nf, B, H):
 
 
 @pytest.mark.parametrize("no_dpp", [False, True])
-def test_custom_mjcf_model_on_the_general_kernels(gpu, orc, no_dpp, monkeypatch):
+def test_custom_mjcf_model_on_the_general_kernels(gpu, orc, no_dpp, monkeypatch, levers):
     """A model only a custom MJCF file produces (tests/custom_models.py: full inertia tensors, 1/2/3-dof hinges with
     springs and dampers, a slide + hinge joint, four children on the root, two colliders on one link) through
     mjcf.load -> mbd_env_create_model -> the general 3-D instantiation, rollouts and one planning step, bit for bit."""
@@ -150,7 +150,7 @@ def test_custom_mjcf_model_on_the_general_kernels(gpu, orc, no_dpp, monkeypatch)
     from test_oracle_physics import _compile
     from mbd_hip.envs.base import RigidBodyEnv
     if no_dpp:
-        monkeypatch.setenv("MBD_NO_DPP", "1")
+        levers(MBD_NO_DPP=1)
     m = _compile(CRAB, env_name="hopper", n_frames=3, reset_noise=0.02, reward_params=(1.0, 0.5))
     F = m.fields
     assert F["iso_inertia"] == 0 and np.abs(F["inv_inertia"][:m.n_links, 3:]).max() > 1.0  # (not even diagonal)
@@ -834,7 +834,7 @@ def test_progress_callback_reads_every_step(gpu):
 
 @pytest.mark.parametrize("mode", ["fused", "aux"])
 @pytest.mark.parametrize("impl", [1, 0])
-def test_noise_prefetch_is_bit_identical(gpu, impl, mode, monkeypatch):
+def test_noise_prefetch_is_bit_identical(gpu, impl, mode, monkeypatch, levers):
     """mbd_plan_prefetch_noise (the NEXT step's normals generated beside the current rollout — in spare workgroups of
     the rollout launch ("fused"), or on the plan's second stream when the rollout fills the chip ("aux", forced here
     by MBD_NO_FUSED_NOISE) — and the candidates formed lazily at the rollout's action fetch and in the weighted mean)
@@ -844,7 +844,7 @@ def test_noise_prefetch_is_bit_identical(gpu, impl, mode, monkeypatch):
     sampler writes Y0s, rollout and weighted mean read it).  Both threefry layouts."""
     monkeypatch.setenv("MBD_THREEFRY_PARTITIONABLE", str(impl))
     if mode == "aux":
-        monkeypatch.setenv("MBD_NO_FUSED_NOISE", "1")
+        levers(MBD_NO_FUSED_NOISE=1)
     import torch
     from mbd_hip.envs import get_env
     from mbd_hip.planners.mbd_planner import Args, Plan
@@ -859,9 +859,9 @@ def test_noise_prefetch_is_bit_identical(gpu, impl, mode, monkeypatch):
     mu1, rm1, rf1, _ = p1.run(key)
     Y1, rewss1, w1 = p1.peek()
     p1.close()
-    monkeypatch.setenv("MBD_NO_LAZY", "1")
+    levers(MBD_NO_LAZY=1)
     p0 = Plan(env, args)
-    monkeypatch.delenv("MBD_NO_LAZY")
+    levers(MBD_NO_LAZY=-1)
     p0.set_state0(st)
     mu0, rm0, rf0, _ = p0.run(key)
     Y0, rewss0, w0 = p0.peek()
@@ -896,13 +896,13 @@ def test_noise_prefetch_is_bit_identical(gpu, impl, mode, monkeypatch):
 
 @pytest.mark.parametrize("no_dpp", [False, True])
 @pytest.mark.parametrize("name,B", [("hopper", 200), ("walker2d", 72), ("halfcheetah", 136), ("cartpole", 100)])
-def test_general_3d_kernels_on_planar_models(gpu, orc_omp, name, B, no_dpp, monkeypatch):
+def test_general_3d_kernels_on_planar_models(gpu, orc_omp, name, B, no_dpp, monkeypatch, levers):
     """The planar models normally run the planar restatement (MBD_FLAG_PLANAR).  Compiled WITHOUT the flag (mjcf.load(
     planar=False) — here: the flag cleared on the compiled model, passed through mbd_env_create_model) they take the
     general 3-D slide-joint kernels (constant slide axes, packed collider pairs, axisymmetric inertia; DPP and shuffle
     exchange), which must stay bit-exact against the 3-D restatement of the checker."""
     if no_dpp:
-        monkeypatch.setenv("MBD_NO_DPP", "1")
+        levers(MBD_NO_DPP=1)
     from conftest import load_model
     from mbd_hip.envs.base import RigidBodyEnv
     from oracle.planner import OracleEnv
@@ -923,13 +923,13 @@ def test_general_3d_kernels_on_planar_models(gpu, orc_omp, name, B, no_dpp, monk
 @pytest.mark.parametrize("no_dpp", [False, True])
 @pytest.mark.parametrize("cls", ["iso", "diag", "full"])
 @pytest.mark.parametrize("name", ["hopper", "walker2d", "tripod", "humanoidrun", "ant"])
-def test_general_3d_kernels_by_inertia_class(gpu, orc, name, cls, no_dpp, monkeypatch):
+def test_general_3d_kernels_by_inertia_class(gpu, orc, name, cls, no_dpp, monkeypatch, levers):
     """launch_rollout picks an instantiation by candidate-group width (4 / 8 / 16 lanes), exchange (a DPP family or
     shuffles) and the CLASS of the model's inverse-inertia tensors: isotropic, axisymmetric, diagonal, full.  The
     built-in models populate only some of the combinations; here the tensors of built-in trees are replaced (the
     checker reads the same model), planar models run their 3-D arithmetic, and every combination is held to the bar."""
     if no_dpp:
-        monkeypatch.setenv("MBD_NO_DPP", "1")
+        levers(MBD_NO_DPP=1)
     from conftest import load_model
     from mbd_hip.envs.base import RigidBodyEnv
     from oracle.planner import OracleEnv
@@ -995,7 +995,7 @@ def test_short_exact_sequences(gpu):
 
 
 @pytest.mark.parametrize("name,N,demo", [("humanoidrun", 300, False), ("humanoidtrack", 192, True), ("car2d", 257, False)])
-def test_phase2_kernel_variants_and_shared_device_are_bit_identical(gpu, name, N, demo, monkeypatch):
+def test_phase2_kernel_variants_and_shared_device_are_bit_identical(gpu, name, N, demo, monkeypatch, levers):
     """Phase 2 has three forms that must give the same bits: score + weighted mean in one launch (the default up to
     12 288 candidates), score_kernel + the tile weighted mean (MBD_NO_FUSED_SCORE=1), score_kernel + the row-major
     two-kernel weighted mean (MBD_WMEAN_SPLIT=1).  And a plan that shares its device with another live plan (it then
@@ -1009,22 +1009,20 @@ def test_phase2_kernel_variants_and_shared_device_are_bit_identical(gpu, name, N
     key = gpu.prng_key(9)
 
     def run(**envs):
-        for k, v in envs.items():
-            monkeypatch.setenv(k, v)
+        levers(**{k: int(v) for k, v in envs.items()})
         p = Plan(env, args)
         p.set_state0(st)
         out = p.run(key)[:3]
         w = p.peek()[2]
         p.close()
-        for k in envs:
-            monkeypatch.delenv(k)
+        levers(**{k: -1 for k in envs})
         return out, w
 
     (mu0, rm0, rf0), w0 = run()
     for envs in (dict(MBD_NO_FUSED_SCORE="1"), dict(MBD_WMEAN_SPLIT="1")):
         (mu, rm, rf), w = run(**envs)
         assert np.array_equal(mu, mu0) and np.array_equal(rm, rm0) and rf == rf0 and np.array_equal(w, w0), envs
-    other = Plan(env, args)  # a second live plan on the device
+    other = Plan(env, args)  # a second live plan on the device (plans no longer count each other: shares_device says it)
     other.set_state0(st)
     (mu, rm, rf), w = run()
     other.close()
@@ -1034,24 +1032,24 @@ def test_phase2_kernel_variants_and_shared_device_are_bit_identical(gpu, name, N
 @pytest.mark.parametrize("name,B,H,sigma", [("humanoidrun", 96, 50, 0.6), ("humanoidrun", 1, 3, 0.3),
                                             ("humanoidrun", 37, 20, 0.9), ("humanoidtrack", 64, 50, 0.4),
                                             ("humanoidtrack", 9, 12, 0.4), ("humanoidstandup", 36, 50, 0.5)])
-def test_pk2_rollout_bitexact(gpu, orc, name, B, H, sigma, monkeypatch):
+def test_pk2_rollout_bitexact(gpu, orc, name, B, H, sigma, monkeypatch, levers):
     """rollout_pk2_kernel — a lane holds its link for the candidates (2k, 2k+1), all arithmetic as v_pk_*_f32 — forced
     with MBD_PK2=1 (launches pick it by themselves only above 4096 candidates) and held to the checker bit for bit,
     odd batch sizes (a half-filled last pair) included."""
-    monkeypatch.setenv("MBD_PK2", "1")
+    levers(MBD_PK2=1)
     _rollout_bitexact(gpu, orc, name, B, H, sigma)
 
 
 @pytest.mark.parametrize("name,B,H", [("humanoidrun", 24, 20), ("humanoidtrack", 16, 20), ("humanoidstandup", 12, 20)])
-def test_pk2_general_instantiations(gpu, orc, name, B, H, monkeypatch):
-    monkeypatch.setenv("MBD_PK2", "1")
+def test_pk2_general_instantiations(gpu, orc, name, B, H, monkeypatch, levers):
+    levers(MBD_PK2=1)
     for k in ("MBD_NO_REWARD_CONST", "MBD_NO_NFR_CONST"):
-        monkeypatch.setenv(k, "1")
+        levers(**{k: 1})
     _rollout_bitexact(gpu, orc, name, B, H, 0.5)
 
 
 @pytest.mark.parametrize("name,B", [("humanoidrun", 8192), ("humanoidtrack", 4100), ("humanoidstandup", 4099)])
-def test_pk2_is_bit_identical_to_the_one_candidate_kernel_at_scale(gpu, name, B, monkeypatch):
+def test_pk2_is_bit_identical_to_the_one_candidate_kernel_at_scale(gpu, name, B, monkeypatch, levers):
     """What a launch of more than 4096 candidates runs by default, against the one-candidate-per-lane kernel on the same
     inputs: rewards, tracked positions and the final link states of every candidate."""
     import torch
@@ -1064,9 +1062,9 @@ def test_pk2_is_bit_identical_to_the_one_candidate_kernel_at_scale(gpu, name, B,
     res = {}
     for k in ("0", "auto"):
         if k == "auto":
-            monkeypatch.delenv("MBD_PK2", raising=False)
+            levers(MBD_PK2=-1)
         else:
-            monkeypatch.setenv("MBD_PK2", k)
+            levers(MBD_PK2=k)
         out = env.rollout(st, us, want_xpos=want, want_final=True)
         res[k] = [o.cpu().numpy() for o in out]
     for a, b in zip(res["0"], res["auto"]):
@@ -1078,7 +1076,7 @@ def test_pk2_is_bit_identical_to_the_one_candidate_kernel_at_scale(gpu, name, B,
                                                   ("humanoidrun", 33, 12, 6, False, "1"), ("humanoidtrack", 128, 50, 8, True, None),
                                                   ("humanoidtrack", 64, 50, 6, True, "1"), ("hopper", 96, 50, 10, False, None),
                                                   ("halfcheetah", 50, 30, 7, False, None), ("ant", 40, 20, 6, False, None)])
-def test_sweep_equals_the_plans_run_alone(gpu, name, N, H, Nd, demo, pk2, monkeypatch):
+def test_sweep_equals_the_plans_run_alone(gpu, name, N, H, Nd, demo, pk2, monkeypatch, levers):
     """SURVEY §8(f) N3 as ONE batched launch per diffusion step (mbd/scripts/run_mbd.py:17-39): every plan of a
     seed sweep — its own key chain and start state — comes out of mbd_sweep_run exactly as out of run_diffusion on its
     own: mu_0ts, per-step mean rewards and the final reward, bit for bit.  pk2 = "1": the sweep's rollout through the
@@ -1089,9 +1087,9 @@ def test_sweep_equals_the_plans_run_alone(gpu, name, N, H, Nd, demo, pk2, monkey
     plans = [Args(seed=s, env_name=name, Nsample=N, Hsample=H, Ndiffuse=Nd, temp_sample=0.1, enable_demo=demo,
                   disable_recommended_params=True, not_render=True) for s in range(5)]
     if pk2 is not None:
-        monkeypatch.setenv("MBD_PK2", pk2)
+        levers(MBD_PK2=pk2)
     rews, mus, _ = run_concurrent(plans, batched=True)
-    monkeypatch.delenv("MBD_PK2", raising=False)
+    levers(MBD_PK2=-1)
     for a, r, mu in zip(plans, rews, mus):
         r_seq, det = run_diffusion(a, return_details=True)
         assert np.array_equal(mu, det["mu_0ts"]), (name, a.seed)
@@ -1145,3 +1143,53 @@ def test_exchange_single_rank_and_argument_checks(gpu):
     gpu.check(lib.mbd_exchange_destroy(h))
     assert lib.mbd_exchange_create(0, 3, 2, 1, 8, C.byref(h)) == gpu.MBD_ERR_INVALID
     assert lib.mbd_exchange_create(0, 0, 99, 1, 8, C.byref(h)) == gpu.MBD_ERR_INVALID
+
+
+# ---- the fallback build (round-2 verdict item 7) -----------------------------------------------------------------------
+_VARIANT_PROBE = r'''
+import sys, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, sys.argv[2])
+from mbd_hip import _capi
+from mbd_hip.envs import get_env
+out = {}
+for name, B, pk2 in (("humanoidrun", 24, -1), ("humanoidrun", 24, 1), ("humanoidstandup", 8, -1), ("ant", 12, -1),
+                     ("hopper", 32, -1), ("halfcheetah", 16, -1), ("cartpole", 32, -1), ("car2d", 16, -1)):
+    _capi.debug_set("MBD_PK2", pk2)
+    env = get_env(name)
+    st = env.reset(_capi.prng_key(5))
+    us = np.clip(np.random.default_rng(B).normal(size=(B, 20, env.action_size)) * 0.6, -1.3, 1.3).astype(np.float32)
+    out[f"{name}_{pk2}"] = env.rollout(st, us).cpu().numpy()
+np.savez(sys.argv[3], lib=np.array(_capi.LIB_PATH if not __import__("os").environ.get("MBD_HIP_LIB") else __import__("os").environ["MBD_HIP_LIB"]), **out)
+'''
+
+
+def test_fallback_build_is_bit_identical(gpu, tmp_path):
+    """The library is built through an assembly post-pass (hipcc -S, tools/fix_straddles.py, assembler, lld, bundler:
+    __graft_entry__.build) that re-encodes instructions without changing the stream; a toolchain that breaks that
+    pipeline gets the plain hipcc build instead.  build() also leaves that plain build under lib/variants/: here one
+    rollout per kernel family (3-D DPP, two candidates per lane, five colliders, ant, three planar families, car2d)
+    runs through BOTH libraries, each in its own process, and must agree bit for bit — and build_mode.txt must say
+    that the library under test did take the assembly path (no silent fallback)."""
+    import subprocess, sys
+    from conftest import ROOT
+    pkg = os.path.join(ROOT, "model-based-diffusion_amd")
+    with open(os.path.join(pkg, "lib", "build_mode.txt")) as f:
+        assert f.read().strip() == "assembly", "the library under test is a fallback build"
+    plain = os.path.join(pkg, "lib", "variants", "libmbd_hip_plain.so")
+    assert os.path.exists(plain), "build() leaves the plain build under lib/variants/"
+    res = {}
+    for tag, lib_path in (("main", None), ("plain", plain)):
+        env = dict(os.environ)
+        env.pop("MBD_HIP_LIB", None)
+        if lib_path:
+            env["MBD_HIP_LIB"] = lib_path
+        out = str(tmp_path / f"{tag}.npz")
+        r = subprocess.run([sys.executable, "-c", _VARIANT_PROBE, ROOT, pkg, out], env=env, capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = np.load(out)
+    assert str(res["plain"]["lib"]).endswith("libmbd_hip_plain.so") and str(res["main"]["lib"]).endswith("libmbd_hip.so")
+    keys = [k for k in res["main"].files if k != "lib"]
+    assert len(keys) == 8
+    for k in keys:
+        assert np.isfinite(res["main"][k]).all() and np.array_equal(res["main"][k], res["plain"][k]), k

@@ -17,10 +17,10 @@ for name, B in (("humanoidrun", 1024), ("humanoidtrack", 2048), ("humanoidstandu
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for it in range(36):
         k = str(it & 1)
-        os.environ["MBD_NO_NFR_CONST"] = k
+        _capi.debug_set("MBD_NO_NFR_CONST", int(k))
         e0.record(); env.rollout(st, us); e1.record(); e1.synchronize()
         if it >= 6:
             ts[k].append(e0.elapsed_time(e1) * 1e3)
     a, b = float(np.median(ts["0"])), float(np.median(ts["1"]))
     print("%-16s B=%4d  NFR constant %.1f us   run-time n_frames %.1f us   (%+.2f %%)" % (name, B, a, b, 100.0 * (b - a) / b))
-os.environ.pop("MBD_NO_NFR_CONST", None)
+_capi.debug_set("MBD_NO_NFR_CONST", -1)

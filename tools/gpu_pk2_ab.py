@@ -1,4 +1,4 @@
-"""Two candidates per lane (mbd_pk2.h, MBD_PK2=1) against one (MBD_PK2=0), same box, ONE process: the switch is read per
+"""Two candidates per lane (mbd_pk2.h, MBD_PK2=1) against one (MBD_PK2=0), same box, ONE process: the lever (mbd_debug_set) is read per
 launch.  Kernel time of env.rollout (HIP events on the launch stream), median of 9, alternating; plus a bit-for-bit
 comparison of the two kernels' rewards at every size."""
 import os, sys
@@ -21,7 +21,7 @@ for name, B in cases:
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for it in range(22):
         k = str(it & 1)
-        os.environ["MBD_PK2"] = k
+        _capi.debug_set("MBD_PK2", int(k))
         e0.record(); r = env.rollout(st, us); e1.record(); e1.synchronize()
         out[k] = r.cpu().numpy()
         if it >= 4:
@@ -29,4 +29,4 @@ for name, B in cases:
     a, b = float(np.median(ts["0"])), float(np.median(ts["1"]))
     same = np.array_equal(out["0"], out["1"])
     print("%-16s B=%6d  one/lane %9.1f us   two/lane %9.1f us   x%.3f   bit-identical: %s" % (name, B, a, b, a / b, same), flush=True)
-os.environ.pop("MBD_PK2", None)
+_capi.debug_set("MBD_PK2", -1)

@@ -6,6 +6,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "model-based-diffusion_amd"))
 import numpy as np
+from mbd_hip import _capi
 from mbd_hip.planners.mbd_planner import Args, run_diffusion
 from mbd_hip.scripts.run_mbd import run_concurrent
 env_name = sys.argv[1] if len(sys.argv) > 1 else "humanoidrun"
@@ -19,13 +20,13 @@ for label, kw, env in (("sweep (two candidates per lane)", dict(batched=True), {
                        ("sweep (one candidate per lane)", dict(batched=True), {"MBD_PK2": "0"}),
                        ("8 streams, round-robin", dict(batched=False), {})):
     for k, v in env.items():
-        os.environ[k] = v
+        _capi.debug_set(k, int(v))
     best = None
     for rep in range(3):
         rews, mus, secs = run_concurrent(plans, **kw)
         best = secs if best is None or secs < best else best
     for k in env:
-        os.environ.pop(k)
+        _capi.debug_set(k, -1)
     out[label] = (best, rews, mus)
     print("%-36s %7.1f ms for %d plans x %d steps = %8.0f plan-steps/s   rew %.3f +- %.3f" %
           (label, best * 1e3, P, Nd - 1, P * (Nd - 1) / best, np.mean(rews), np.std(rews)), flush=True)
