@@ -94,7 +94,7 @@ def pmc_traffic(config):
         return None, None
     ent = d.get(config) or (d if config == "metric" else {})
     for k, v in ent.items():
-        if isinstance(v, dict) and "rollout_kernel" in k and "hbm_bytes_per_launch_corrected" in v:
+        if isinstance(v, dict) and "rollout_" in k and "_kernel" in k and "car2d" not in k and "hbm_bytes_per_launch_corrected" in v:
             return v["hbm_bytes_per_launch_corrected"], src
     return None, None
 

@@ -44,13 +44,15 @@ def count(targs):
         kern, hdr = "rollout_kernel", "mbd_kernels.h"
         if targs.startswith("planar:"):
             kern, hdr, targs = "rollout_planar_kernel", "mbd_planar.h", targs[len("planar:"):]
+        extra = []
         if targs.startswith("pk2:"):
             kern, hdr, targs = "rollout_pk2_kernel", "mbd_pk2.h", targs[len("pk2:"):]
+            extra = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]  # (the flags of its translation unit: build())
         with open(src, "w") as f:
             f.write(f'#include "{csrc}/{hdr}"\ntemplate __global__ void mbd::{kern}<{targs}>(mbd::RolloutParams);\n')
         out = os.path.join(td, "k.s")
         subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off",
-                        "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", *os.environ.get("MBD_COUNT_DEFS", "").split(),
+                        "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", *extra, *os.environ.get("MBD_COUNT_DEFS", "").split(),
                         "-S", "--cuda-device-only", src, "-o", out], check=True, capture_output=True)
         body = open(out).read().split("\n")
     start = [i for i, l in enumerate(body) if re.match(r"^_ZN3mbd\d+rollout_(planar_|pk2_)?kernel.*:", l)][0]
@@ -127,7 +129,7 @@ def count(targs):
 
 
 def main():
-    tag = next((a for a in sys.argv[1:] if a.startswith("r") and a[1:].isdigit()), "r02")
+    tag = next((a for a in sys.argv[1:] if a.startswith("r") and a[1:].isdigit()), "r03")
     envs = [a for a in sys.argv[1:] if a in INSTANCES] or list(INSTANCES)
     out = {}
     for env in envs:

@@ -17,7 +17,7 @@ from oracle import oracle as orc_mod  # noqa: E402
 
 
 def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
     orc_mod.build()
     orc = orc_mod.Oracle("f32")
     out = {}
