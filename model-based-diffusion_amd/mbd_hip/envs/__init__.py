@@ -9,7 +9,8 @@ __all__ = ["get_env", "State", "Car2d", "RigidBodyEnv"]
 
 def get_env(env_name: str, device: int = 0):
     """Same contract as the reference: a string in, an env object out, ``ValueError`` on an unknown
-    name.  In scope: car2d, hopper, halfcheetah, humanoidrun, humanoidtrack."""
+    name.  Every name the reference's registry knows resolves — car2d, humanoidrun, humanoidtrack, humanoidstandup, hopper,
+    halfcheetah, walker2d, cartpole, ant — except pushT (Brax's generalized backend: another physics engine)."""
     if env_name == "car2d":
         return Car2d(device=device)
     if env_name in specs.SPECS:
