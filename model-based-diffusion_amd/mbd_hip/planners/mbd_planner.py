@@ -249,20 +249,37 @@ class P2PExchange:
     windows travel once, at construction, through the process group (any backend)."""
 
     def __init__(self, device: int, rows: int, shard: int, group=None):
+        """Collective over ``group``: every rank must construct it.  A failure on ANY rank (no IPC, no peer access) is
+        agreed on before anybody returns — all ranks raise, nobody is left waiting in a collective."""
+        import torch
         import torch.distributed as dist
         self.lib = _capi.load()
         self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
         self.rows, self.shard = rows, shard
-        h = C.c_void_p()
-        _capi.check(self.lib.mbd_exchange_create(device, self.rank, self.world, rows, shard, C.byref(h)))
-        self.h = h
+        self.h = None
+        why = None
         mine = (C.c_ubyte * 64)()
-        _capi.check(self.lib.mbd_exchange_local_handle(self.h, mine))
+        try:
+            h = C.c_void_p()
+            _capi.check(self.lib.mbd_exchange_create(device, self.rank, self.world, rows, shard, C.byref(h)))
+            self.h = h
+            _capi.check(self.lib.mbd_exchange_local_handle(self.h, mine))
+        except Exception as e:  # noqa: BLE001
+            why = f"rank {self.rank}: {e}"
         handles = [None] * self.world
         dist.all_gather_object(handles, bytes(mine), group=group)
-        blob = (C.c_ubyte * (64 * self.world)).from_buffer_copy(b"".join(handles))
-        _capi.check(self.lib.mbd_exchange_connect(self.h, blob))
-        dist.barrier(group)  # every window is mapped everywhere before the first push
+        if why is None:
+            try:
+                blob = (C.c_ubyte * (64 * self.world)).from_buffer_copy(b"".join(handles))
+                _capi.check(self.lib.mbd_exchange_connect(self.h, blob))
+            except Exception as e:  # noqa: BLE001
+                why = f"rank {self.rank}: {e}"
+        on_gpu = dist.get_backend(group) == "nccl"
+        ok = torch.tensor([0 if why else 1], dtype=torch.int32, device=torch.device("cuda", device) if on_gpu else "cpu")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)  # (also the barrier: every window is mapped everywhere)
+        if int(ok.item()) == 0:
+            self.close()
+            raise _capi.MbdError(_capi.MBD_ERR_STATE, why or "the in-library exchange could not be set up on another rank")
 
     def all_gather(self, local, stream: int) -> int:
         """local: CUDA tensor [rows, shard].  Returns the device address of the gathered [rows, world * shard] values

@@ -1193,3 +1193,20 @@ def test_fallback_build_is_bit_identical(gpu, tmp_path):
     assert len(keys) == 8
     for k in keys:
         assert np.isfinite(res["main"][k]).all() and np.array_equal(res["main"][k], res["plain"][k]), k
+
+
+def test_exchange_reports_a_peer_that_never_arrives(gpu, tmp_path):
+    """A rank whose peer never pushes: its waits end at their time limit (~2 s of the wall clock, once — the flag is
+    sticky), mbd_exchange_status turns that into MBD_ERR_STATE, and the process returns instead of hanging."""
+    import json, socket, subprocess, sys
+    from conftest import ROOT
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "exchange_timeout_worker.py"), str(tmp_path)]
+    out = subprocess.run(cmd, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r0 = json.load(open(os.path.join(tmp_path, "xt_rank0.json")))
+    assert r0["error"] is not None and "time limit" in r0["error"], r0
+    assert 1.0 < r0["seconds"] < 8.0, r0  # one limit, not four
