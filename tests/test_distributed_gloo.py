@@ -77,3 +77,41 @@ def test_world2_gloo_matches_single_process_bitwise(orc, tmp_path):
     mu1 = np.load(tmp_path / "mu_1.npy")
     assert np.array_equal(mu0, mu1), "ranks disagree"
     assert np.array_equal(mu0, ref), "sharded result differs from the single-process result"
+
+
+def _allreduce_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    for p in (ROOT, os.path.join(ROOT, "model-based-diffusion_amd")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from mbd_hip.planners.mbd_planner import exchange_rewards
+    g = np.random.default_rng(7)
+    allv = g.normal(size=(2, 96)).astype(np.float32)       # the same on every rank; each owns one slice of it
+    allv[0, 5], allv[1, 50] = 0.0, -0.0
+    sh = 96 // world
+    local = torch.from_numpy(np.ascontiguousarray(allv[:, rank * sh:(rank + 1) * sh]))
+    gathered = exchange_rewards(local, world).numpy()
+    padded = torch.zeros((2, 96), dtype=torch.float32)
+    padded[:, rank * sh:(rank + 1) * sh] = local
+    dist.all_reduce(padded, op=dist.ReduceOp.SUM)          # the north star's wording: "a single all-reduce"
+    np.savez(os.path.join(out, f"ar_{rank}.npz"), gathered=gathered, reduced=padded.numpy(), want=allv)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_allreduce_of_the_zero_padded_vector_is_the_allgather(tmp_path):
+    """the step's one collective is an all-gather of the per-candidate rewards; the north star words it as an
+    all-reduce.  An all-reduce (sum) of every rank's slice padded with zeros delivers the same VALUES — x + 0 + ... + 0 is
+    exact in any order — and the same bits except that a reward of exactly -0.0 comes back as +0.0 (-0 + +0 = +0), which
+    no later step of the score distinguishes (sums, differences, max).  World size 3 so that the order of the ring
+    matters if anything does."""
+    port = 29500 + ((os.getpid() + 7) % 2000)
+    mp.spawn(_allreduce_worker, args=(3, port, str(tmp_path)), nprocs=3, join=True)
+    for r in range(3):
+        d = np.load(tmp_path / f"ar_{r}.npz")
+        assert np.array_equal(d["gathered"], d["want"]) and np.array_equal(d["gathered"].view(np.uint32), d["want"].view(np.uint32))
+        assert np.array_equal(d["reduced"], d["want"])     # the same values ...
+        diff = d["reduced"].view(np.uint32) != d["want"].view(np.uint32)
+        assert diff.sum() == 1 and diff[1, 50]              # ... and the same bits but for the one -0.0
