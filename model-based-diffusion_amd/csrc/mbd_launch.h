@@ -39,9 +39,10 @@ inline hipError_t launch_rollout_kernel(K kernel, int device, dim3 grid, dim3 bl
 // the two-candidates-per-lane rollouts of the humanoid family (mbd_pk2.h; their own translation unit, mbd_pk2.hip, built
 // with the scheduler strategy that keeps dependent packed instructions apart).  hipErrorInvalidValue: no such instantiation.
 // wpe: 2 asks for the instantiation whose registers leave room for two wavefronts per SIMD (where there is one).
-hipError_t launch_rollout_pk2(int maxcol, int rk, int nfr, int wpe, int device, dim3 grid, dim3 block, size_t lds,
+// fam: 0 the humanoid family, 1 ant (mbd_pk2.h)
+hipError_t launch_rollout_pk2(int fam, int maxcol, int rk, int nfr, int wpe, int device, dim3 grid, dim3 block, size_t lds,
                               hipStream_t stream, const RolloutParams& P);
 // (maxcol, rk, nfr) the launcher would run for a model with `max_col` colliders per link, reward kind `rk`, `nfr` frames
-bool pk2_instantiation(int max_col, int rk, int nfr, int out[3]);
+bool pk2_instantiation(int fam, int max_col, int rk, int nfr, int out[3]);
 
 }  // namespace mbd

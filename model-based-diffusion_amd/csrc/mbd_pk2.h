@@ -111,6 +111,7 @@ struct JointFramesP {
   v3x2 Xp, Xc, Yc, Zc, ax1;
   f2 ang0, ang1, ang2;
 };
+template <bool MULTI = true>
 __device__ __forceinline__ JointFramesP joint_frames_p(const JointConst& jc, v3x2 Pp, q4x2 Pr, v3x2 Cp, q4x2 Cr) {
   JointFramesP f;
   f.rp = rot2(bcast3(jc.ap_pos), Pr);
@@ -125,9 +126,14 @@ __device__ __forceinline__ JointFramesP joint_frames_p(const JointConst& jc, v3x
   const f2 cb = sqrt_floor2(cb2);
   const f2 inv = rcp_exact2(cb + splat(1e-10f));
   f.ang0 = angle_unit2((-dot2(C.Z, A.Y)) * inv, dot2(C.Z, A.Z) * inv);
-  f.ang1 = angle_unit_cpos2(sb, cb);
-  f.ang2 = angle_unit2((-dot2(C.Y, A.X)) * inv, dot2(C.X, A.X) * inv);
-  f.ax1 = scale2(cross2(C.Z, A.X), inv);
+  if constexpr (MULTI) {
+    f.ang1 = angle_unit_cpos2(sb, cb);
+    f.ang2 = angle_unit2((-dot2(C.Y, A.X)) * inv, dot2(C.X, A.X) * inv);
+    f.ax1 = scale2(cross2(C.Z, A.X), inv);
+  } else {  // single-hinge models only ever use the first Euler angle and axis (joint_frames of mbd_kernels.h)
+    f.ang1 = f.ang2 = splat(0.0f);
+    f.ax1 = zero3x2();
+  }
   return f;
 }
 
@@ -138,37 +144,59 @@ __device__ __forceinline__ JointFramesP joint_frames_p(const JointConst& jc, v3x
   MBD_PF(0, 12, M, MOD) MBD_PF(1, 13, M, MOD) MBD_PF(2, 14, M, MOD) MBD_PF(3, 15, M, MOD) MBD_PF(4, 16, M, MOD)  \
   MBD_PF(5, 17, M, MOD) MBD_PF(6, 18, M, MOD) MBD_PF(7, 19, M, MOD) MBD_PF(8, 20, M, MOD) MBD_PF(9, 21, M, MOD)  \
   MBD_PF(10, 22, M, MOD) MBD_PF(11, 23, M, MOD)
-__device__ __forceinline__ void dpp_acc6x3_p(v3x2& a, v3x2& b, v3x2 x, v3x2 y, float m0, float m1, float m2) {
+#define MBD_PK2_ACC_IO                                                                                            \
+      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9), "+v"(a10), \
+        "+v"(a11)                                                                                                 \
+      : "v"(x.x.x), "v"(x.y.x), "v"(x.z.x), "v"(y.x.x), "v"(y.y.x), "v"(y.z.x), "v"(x.x.y), "v"(x.y.y), "v"(x.z.y), \
+        "v"(y.x.y), "v"(y.y.y), "v"(y.z.y), "v"(m[0]), "v"(m[1]), "v"(m[2]), "v"(m[3])
+// FAM: the DPP layout family — 0: the humanoids (a link's children sit at lane - 1, + 4, + 6), 1: ant (- 1, + 2, + 4, + 6)
+template <int FAM>
+__device__ __forceinline__ void dpp_acc_p(v3x2& a, v3x2& b, v3x2 x, v3x2 y, const float (&m)[4]) {
   float a0 = a.x.x, a1 = a.y.x, a2 = a.z.x, a3 = b.x.x, a4 = b.y.x, a5 = b.z.x;
   float a6 = a.x.y, a7 = a.y.y, a8 = a.z.y, a9 = b.x.y, a10 = b.y.y, a11 = b.z.y;
-  asm("s_nop 1\n\t" MBD_PF12("row_shr:1", 24) MBD_PF12("row_shl:4", 25) MBD_PF12("row_shl:6", 26)
-      : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7), "+v"(a8), "+v"(a9), "+v"(a10),
-        "+v"(a11)
-      : "v"(x.x.x), "v"(x.y.x), "v"(x.z.x), "v"(y.x.x), "v"(y.y.x), "v"(y.z.x), "v"(x.x.y), "v"(x.y.y), "v"(x.z.y),
-        "v"(y.x.y), "v"(y.y.y), "v"(y.z.y), "v"(m0), "v"(m1), "v"(m2));
+  if constexpr (FAM == 0) {
+    asm("s_nop 1\n\t" MBD_PF12("row_shr:1", 24) MBD_PF12("row_shl:4", 25) MBD_PF12("row_shl:6", 26) MBD_PK2_ACC_IO);
+  } else {
+    asm("s_nop 1\n\t" MBD_PF12("row_shr:1", 24) MBD_PF12("row_shl:2", 25) MBD_PF12("row_shl:4", 26) MBD_PF12("row_shl:6", 27)
+        MBD_PK2_ACC_IO);
+  }
   a = v3x2{mk2(a0, a6), mk2(a1, a7), mk2(a2, a8)};
   b = v3x2{mk2(a3, a9), mk2(a4, a10), mk2(a5, a11)};
 }
+#undef MBD_PK2_ACC_IO
 #undef MBD_PF12
 #define MBD_PF14(MOD, M)                                                                                         \
   MBD_PF(0, 14, M, MOD) MBD_PF(1, 15, M, MOD) MBD_PF(2, 16, M, MOD) MBD_PF(3, 17, M, MOD) MBD_PF(4, 18, M, MOD)  \
   MBD_PF(5, 19, M, MOD) MBD_PF(6, 20, M, MOD) MBD_PF(7, 21, M, MOD) MBD_PF(8, 22, M, MOD) MBD_PF(9, 23, M, MOD)  \
   MBD_PF(10, 24, M, MOD) MBD_PF(11, 25, M, MOD) MBD_PF(12, 26, M, MOD) MBD_PF(13, 27, M, MOD)
-__device__ __forceinline__ void dpp_fetch7_p(v3x2 p, q4x2 r, float m0, float m1, float m2, v3x2& Pp, q4x2& Pr) {
+#define MBD_PK2_FETCH_OUT                                                                                         \
+      : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(o4), "+v"(o5), "+v"(o6), "+v"(o7), "+v"(o8), "+v"(o9), "+v"(o10), \
+        "+v"(o11), "+v"(o12), "+v"(o13)
+#define MBD_PK2_FETCH_IN                                                                                          \
+      "v"(p.x.x), "v"(p.y.x), "v"(p.z.x), "v"(r.w.x), "v"(r.x.x), "v"(r.y.x), "v"(r.z.x), "v"(p.x.y), "v"(p.y.y),  \
+        "v"(p.z.y), "v"(r.w.y), "v"(r.x.y), "v"(r.y.y), "v"(r.z.y)
+template <int FAM>
+__device__ __forceinline__ void dpp_fetch_p(v3x2 p, q4x2 r, const float (&m)[4], v3x2& Pp, q4x2& Pr) {
+  const float m0 = m[0];
   float o0 = dpp_from<1>(p.x.x) * m0, o1 = dpp_from<1>(p.y.x) * m0, o2 = dpp_from<1>(p.z.x) * m0;
   float o3 = dpp_from<1>(r.w.x) * m0, o4 = dpp_from<1>(r.x.x) * m0, o5 = dpp_from<1>(r.y.x) * m0;
   float o6 = dpp_from<1>(r.z.x) * m0;
   float o7 = dpp_from<1>(p.x.y) * m0, o8 = dpp_from<1>(p.y.y) * m0, o9 = dpp_from<1>(p.z.y) * m0;
   float o10 = dpp_from<1>(r.w.y) * m0, o11 = dpp_from<1>(r.x.y) * m0, o12 = dpp_from<1>(r.y.y) * m0;
   float o13 = dpp_from<1>(r.z.y) * m0;
-  asm("s_nop 1\n\t" MBD_PF14("row_shr:4", 28) MBD_PF14("row_shr:6", 29)
-      : "+v"(o0), "+v"(o1), "+v"(o2), "+v"(o3), "+v"(o4), "+v"(o5), "+v"(o6), "+v"(o7), "+v"(o8), "+v"(o9), "+v"(o10),
-        "+v"(o11), "+v"(o12), "+v"(o13)
-      : "v"(p.x.x), "v"(p.y.x), "v"(p.z.x), "v"(r.w.x), "v"(r.x.x), "v"(r.y.x), "v"(r.z.x), "v"(p.x.y), "v"(p.y.y),
-        "v"(p.z.y), "v"(r.w.y), "v"(r.x.y), "v"(r.y.y), "v"(r.z.y), "v"(m1), "v"(m2));
+  if constexpr (FAM == 0) {
+    asm("s_nop 1\n\t" MBD_PF14("row_shr:4", 28) MBD_PF14("row_shr:6", 29) MBD_PK2_FETCH_OUT
+        : MBD_PK2_FETCH_IN, "v"(m[1]), "v"(m[2]));
+  } else {  // (30 operands at most per block: the fourth slot in a block of its own)
+    asm("s_nop 1\n\t" MBD_PF14("row_shr:2", 28) MBD_PF14("row_shr:4", 29) MBD_PK2_FETCH_OUT
+        : MBD_PK2_FETCH_IN, "v"(m[1]), "v"(m[2]));
+    asm("s_nop 1\n\t" MBD_PF14("row_shr:6", 28) MBD_PK2_FETCH_OUT : MBD_PK2_FETCH_IN, "v"(m[3]));
+  }
   Pp = v3x2{mk2(o0, o7), mk2(o1, o8), mk2(o2, o9)};
   Pr = q4x2{mk2(o3, o10), mk2(o4, o11), mk2(o5, o12), mk2(o6, o13)};
 }
+#undef MBD_PK2_FETCH_IN
+#undef MBD_PK2_FETCH_OUT
 #undef MBD_PF14
 #undef MBD_PF
 
@@ -179,8 +207,11 @@ __device__ __forceinline__ void dpp_fetch7_p(v3x2 p, q4x2 r, float m0, float m1,
 //      candidates on 256 CUs).  2: capped at 256 — 23 scratch accesses per CONTROL step, none in the substep loop — so
 //      that larger launches run two wavefronts per SIMD, whose instruction fetches and hazard wait states overlap
 //      (N = 32768: 3.60 -> 3.39 ms; N = 8192, one wavefront per SIMD either way: 0.97 -> 1.09 ms)
-template <int MAXCOL, int RK = -1, int NFR = 0, int WPE = 1>
+// FAM: 0 the humanoid family (three child slots, multi-dof joints), 1 ant (four child slots, single hinges, the
+//      control-cost reward: the action row of the next control step travels with the other prefetched actions)
+template <int MAXCOL, int RK = -1, int NFR = 0, int WPE = 1, int FAM = 0>
 __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) {
+  constexpr bool MULTI = FAM == 0;
   if ((int)blockIdx.x >= P.roll_blocks) {  // the next step's normals, on CUs the rollout leaves idle
     noise_blocks(P);
     return;
@@ -221,9 +252,9 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
     act_rot[k] = R.act_rot[k];
     gear_rot[k] = R.gear_rot[k]; alo_rot[k] = R.alo_rot[k]; ahi_rot[k] = R.ahi_rot[k];
   }
-  float rm[3], pm[3];
+  float rm[4], pm[4];
 #pragma unroll
-  for (int k = 0; k < 3; ++k) { rm[k] = R.rm[k]; pm[k] = R.pm[k]; }
+  for (int k = 0; k < 4; ++k) { rm[k] = R.rm[k]; pm[k] = R.pm[k]; }
   v3 col_pos[MAXCOL];
   float col_rad[MAXCOL];
   bool col_has[MAXCOL];
@@ -242,6 +273,8 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
   const float mu = Mg->friction, elast = Mg->elasticity;
   const v3 grav = mk3(Mg->gravity[0], Mg->gravity[1], Mg->gravity[2]);
   const int rkind = RK >= 0 ? RK : Mg->reward_kind;
+  const float rp0 = Mg->reward_params[0], rp1 = Mg->reward_params[1];
+  const float dt_ctrl = Mg->dt * (float)nfr;
 
   // ---- state: both candidates start from the same state0 --------------------------------------------------
   const int pl = plan_of(P, bA);  // (sweeps: plans hold an even number of candidates, a pair never straddles two)
@@ -275,6 +308,21 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
     for (int k = 0; k < 3; ++k) yr[k] = yb_row[(size_t)t * Nu + (act_rot[k] >= 0 ? act_rot[k] : 0)];
   };
   load_actions(0, u_rot, y_rot);
+  // control cost (ant): the whole action row of both candidates, in actuator order (rollout_kernel's cc_* prefetch)
+  constexpr int KCC = FAM == 1 ? 8 : 0;
+  f2 cc_u[KCC + 1], ccn_u[KCC + 1];
+  float cc_y[KCC + 1], ccn_y[KCC + 1];
+  auto load_row = [&](int t, f2 (&ru)[KCC + 1], float (&ry)[KCC + 1]) {
+#pragma unroll
+    for (int k = 0; k < KCC; ++k) {
+      const size_t o = (size_t)t * Nu + (k < Nu ? k : 0);
+      ru[k] = mk2(uA[o], uB[o]);
+      ry[k] = yb_row[o];
+    }
+  };
+#pragma unroll
+  for (int k = 0; k < KCC + 1; ++k) { cc_u[k] = ccn_u[k] = splat(0.0f); cc_y[k] = ccn_y[k] = 0.0f; }
+  if constexpr (KCC > 0) load_row(0, cc_u, cc_y);
   v3x2 Pp_next = shfl3x2(p, plane);
   q4x2 Pr_next = shfl4x2(r, plane);
   f2 rew_sum = splat(0.0f);
@@ -286,11 +334,24 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
       u_rot[k] = cand(u_rot[k], y_rot[k]);
       tau[k] = fclip2(act_rot[k] >= 0 ? u_rot[k] : splat(0.0f), alo_rot[k], ahi_rot[k]) * splat(gear_rot[k]);
     }
+    f2 ctrl_cost = splat(0.0f);
+    if constexpr (KCC > 0) {
+#pragma unroll
+      for (int k = 0; k < KCC; ++k) {
+        const f2 ua = cand(cc_u[k], cc_y[k]);
+        ctrl_cost = k < Nu ? ctrl_cost + ua * ua : ctrl_cost;
+      }
+      for (int a = KCC; a < Nu; ++a) {
+        const f2 ua = cand(mk2(uA[(size_t)t * Nu + a], uB[(size_t)t * Nu + a]), yb_row[(size_t)t * Nu + a]);
+        ctrl_cost = ctrl_cost + ua * ua;
+      }
+    }
     load_actions(t + 1 < H ? t + 1 : t, un_rot, yn_rot);
+    if constexpr (KCC > 0) load_row(t + 1 < H ? t + 1 : t, ccn_u, ccn_y);
     __builtin_amdgcn_sched_barrier(0);
     // link-frame origin before the step (the tracking reward looks at the incoming state)
     v3x2 o0 = zero3x2(), v0 = zero3x2();
-    if (rkind == MBD_REW_HUMANOIDTRACK) {
+    if (rkind == MBD_REW_HUMANOIDTRACK || rkind == MBD_REW_ANT) {
       const v3x2 rc0 = rot2(bcast3(com), r);
       o0 = sub2(p, rc0);
       v0 = sub2(v, cross2(w, rc0));
@@ -304,7 +365,7 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
       q4x2 Pr = Pr_next;
       v3x2 fc_v, fc_w, fp_v, fp_w;
       {
-        const JointFramesP f = joint_frames_p(jc, Pp, Pr, p, r);
+        const JointFramesP f = joint_frames_p<MULTI>(jc, Pp, Pr, p, r);
         shfl_join();
         const v3x2 vp = add2(Pv, cross2(Pw, f.rp)), vc = add2(v, cross2(w, f.rc));  // anchor velocities
         const v3x2 rel_v = sub2(vc, vp), rel_w = sub2(w, Pw);
@@ -316,8 +377,10 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
           T = axpy2(fk, ax, T);
         };
         torque(0, f.Xp, f.ang0);
-        torque(1, f.ax1, f.ang1);
-        torque(2, f.Zc, f.ang2);
+        if constexpr (MULTI) {
+          torque(1, f.ax1, f.ang1);
+          torque(2, f.Zc, f.ang2);
+        }
         T = axpy2(splat(-ang_damp), rel_w, T);
         const v3x2 F = axpy2(splat(-vel_damp), rel_v, zero3x2());
         fp_v = scale2s(F, -ip_inv_mass);
@@ -329,7 +392,7 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
       // ---- (2) integrator.integrate_xdd -------------------------------------------------------------
       {
         v3x2 sv = fc_v, sw = fc_w;
-        dpp_acc6x3_p(sv, sw, fp_v, fp_w, rm[0], rm[1], rm[2]);
+        dpp_acc_p<FAM>(sv, sw, fp_v, fp_w, rm);
         const f2 vf = splat(vel_fac), af = splat(ang_fac), dt2 = splat(dt);
         v = v3x2{fma2(sv.x + splat(grav.x), dt2, vf * v.x), fma2(sv.y + splat(grav.y), dt2, vf * v.y),
                  fma2(sv.z + splat(grav.z), dt2, vf * v.z)};
@@ -340,9 +403,9 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
       p = v3x2{fma2(v.x, splat(dt), p.x), fma2(v.y, splat(dt), p.y), fma2(v.z, splat(dt), p.z)};
       r = qrotvec2(r, scale2s(w, dt));
       // ---- (3) joints.position_update (Jacobi) ------------------------------------------------------
-      dpp_fetch7_p(p, r, pm[0], pm[1], pm[2], Pp, Pr);
+      dpp_fetch_p<FAM>(p, r, pm, Pp, Pr);
       {
-        const JointFramesP f = joint_frames_p(jc, Pp, Pr, p, r);
+        const JointFramesP f = joint_frames_p<MULTI>(jc, Pp, Pr, p, r);
         const v3x2 d = sub2(f.ap, f.ac);
         const f2 c2 = dot2(d, d);
         const v3x2 crp = cross2(f.rp, d), crc = cross2(f.rc, d);
@@ -356,8 +419,10 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
         v3x2 E = scale2(cross2(A, Bv), sc);
         auto viol_of = [&](int k, f2 a) { return k < nr_eff ? a - fclip2(a, lim_lo[k], lim_hi[k]) : splat(0.0f); };
         E = axpy2(-viol_of(0, f.ang0), f.Xp, E);
-        E = axpy2(-viol_of(1, f.ang1), f.ax1, E);
-        E = axpy2(-viol_of(2, f.ang2), f.Zc, E);
+        if constexpr (MULTI) {
+          E = axpy2(-viol_of(1, f.ang1), f.ax1, E);
+          E = axpy2(-viol_of(2, f.ang2), f.Zc, E);
+        }
         const f2 g = div2_pos_(c2, den) * splat(js_pos);
         const v3x2 Pi = scale2(d, g);
         const v3x2 dp_p = scale2s(Pi, -ip_inv_mass);
@@ -366,7 +431,7 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
         v3x2 dc_th = scale2s(cross2(f.rc, Pi), ic_ib);
         dp_th = axpy2(splat(kang_p), E, dp_th);
         dc_th = axpy2(splat(kang_c), E, dc_th);
-        dpp_acc6x3_p(dc_p, dc_th, dp_p, dp_th, rm[0], rm[1], rm[2]);
+        dpp_acc_p<FAM>(dc_p, dc_th, dp_p, dp_th, rm);
         p = add2(p, dc_p);
         r = qrotvec_raw2(r, dc_th);  // renormalised at the end of stage (4)
       }
@@ -468,6 +533,13 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
         rew = o1.x * splat(1.0f) - fclip2(fabs2(o1.z - splat(1.3f)), -1.0f, 1.0f) * splat(1.0f) - fabs2(o1.y) * splat(0.1f);
       } else if (rkind == MBD_REW_HUMANOIDSTANDUP) {
         rew = splat(1.5f) - fclip2(fabs2(o1.z - splat(1.3f)), -2.0f, 1.0f) - fabs2(o1.x) * splat(0.1f) - fabs2(o1.y) * splat(0.1f);
+      } else if (rkind == MBD_REW_ANT) {  // (rollout_kernel's expression per half: the divisions are IEEE)
+        const bool always = Mg->reward_params[5] != 0.0f;
+        const float zlo = Mg->reward_params[2], zhi = Mg->reward_params[3], hv = Mg->reward_params[4];
+        const f2 healthy = mk2((always || (o1.z.x >= zlo && o1.z.x <= zhi)) ? hv : 0.0f,
+                               (always || (o1.z.y >= zlo && o1.z.y <= zhi)) ? hv : 0.0f);
+        const f2 fwd = mk2((o1.x.x - o0.x.x) / dt_ctrl, (o1.x.y - o0.x.y) / dt_ctrl);
+        rew = (splat(rp0) * fwd + healthy) - splat(rp1) * ctrl_cost;
       } else {  // MBD_REW_HUMANOIDTRACK: the reward of the INCOMING state (humanoidtrack.py:78)
         rew = splat(1.0f) + (-fabs2(v0.x - splat(1.6f)) - fabs2(o0.z - splat(1.3f)) - fabs2(o0.y) * splat(0.1f));
       }
@@ -489,6 +561,8 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
     }
 #pragma unroll
     for (int k = 0; k < 3; ++k) { u_rot[k] = un_rot[k]; y_rot[k] = yn_rot[k]; }
+#pragma unroll
+    for (int k = 0; k < KCC; ++k) { cc_u[k] = ccn_u[k]; cc_y[k] = ccn_y[k]; }
   }  // control steps
   if (root_lane && P.rews) {
     if (okA) P.rews[bA] = rew_sum.x / (float)H;

@@ -9,7 +9,14 @@
 
 namespace mbd {
 
-bool pk2_instantiation(int max_col, int rk, int nfr, int out[3]) {
+// fam: 0 humanoid-shaped, 1 ant-shaped (mbd_pk2.h); out = (MAXCOL, RK, NFR) of the instantiation that serves the model
+bool pk2_instantiation(int fam, int max_col, int rk, int nfr, int out[3]) {
+  if (fam == 1) {
+    if (max_col > 2 || rk != MBD_REW_ANT) return false;
+    out[0] = 2; out[1] = -1; out[2] = 0;
+    if (nfr == 10) { out[1] = rk; out[2] = 10; }
+    return true;
+  }
   if (max_col > 5) return false;
   if (rk != MBD_REW_HUMANOIDRUN && rk != MBD_REW_HUMANOIDTRACK && rk != MBD_REW_HUMANOIDSTANDUP) return false;
   out[0] = max_col <= 1 ? 1 : 5;
@@ -21,9 +28,16 @@ bool pk2_instantiation(int max_col, int rk, int nfr, int out[3]) {
   return true;
 }
 
-hipError_t launch_rollout_pk2(int maxcol, int rk, int nfr, int wpe, int device, dim3 grid, dim3 block, size_t lds,
+hipError_t launch_rollout_pk2(int fam, int maxcol, int rk, int nfr, int wpe, int device, dim3 grid, dim3 block, size_t lds,
                               hipStream_t stream, const RolloutParams& P) {
 #define PK(...) return launch_rollout_kernel(rollout_pk2_kernel<__VA_ARGS__>, device, grid, block, lds, stream, P)
+  if (fam == 1) {  // ant (the reference's default env_name: mbd_planner.py:28, run_mbd.py:14)
+    // (capped at 256 registers for two wavefronts per SIMD it is SLOWER here — 78 scratch accesses per control step:
+    // N = 16384 2.71 -> 2.95 ms — so ant always runs the one-wavefront-per-SIMD form)
+    if (maxcol == 2 && rk == MBD_REW_ANT && nfr == 10) PK(2, MBD_REW_ANT, 10, 1, 1);
+    if (maxcol == 2 && rk == -1 && nfr == 0) PK(2, -1, 0, 1, 1);
+    return hipErrorInvalidValue;
+  }
   // (two wavefronts per SIMD: the reference's own humanoids with one collider per link; humanoidstandup's five
   // colliders do not fit 256 registers without spilling inside the substep loop — N = 16384: 4.36 -> 4.57 ms)
   if (wpe == 2 && maxcol == 1 && rk == MBD_REW_HUMANOIDRUN && nfr == 7) PK(1, MBD_REW_HUMANOIDRUN, 7, 2);

@@ -1031,7 +1031,8 @@ def test_phase2_kernel_variants_and_shared_device_are_bit_identical(gpu, name, N
 # ---- two candidates per lane (mbd_pk2.h) -----------------------------------------------------------------------------
 @pytest.mark.parametrize("name,B,H,sigma", [("humanoidrun", 96, 50, 0.6), ("humanoidrun", 1, 3, 0.3),
                                             ("humanoidrun", 37, 20, 0.9), ("humanoidtrack", 64, 50, 0.4),
-                                            ("humanoidtrack", 9, 12, 0.4), ("humanoidstandup", 36, 50, 0.5)])
+                                            ("humanoidtrack", 9, 12, 0.4), ("humanoidstandup", 36, 50, 0.5),
+                                            ("ant", 44, 50, 0.5), ("ant", 7, 20, 0.9)])
 def test_pk2_rollout_bitexact(gpu, orc, name, B, H, sigma, monkeypatch, levers):
     """rollout_pk2_kernel — a lane holds its link for the candidates (2k, 2k+1), all arithmetic as v_pk_*_f32 — forced
     with MBD_PK2=1 (launches pick it by themselves only above 4096 candidates) and held to the checker bit for bit,
@@ -1040,7 +1041,8 @@ def test_pk2_rollout_bitexact(gpu, orc, name, B, H, sigma, monkeypatch, levers):
     _rollout_bitexact(gpu, orc, name, B, H, sigma)
 
 
-@pytest.mark.parametrize("name,B,H", [("humanoidrun", 24, 20), ("humanoidtrack", 16, 20), ("humanoidstandup", 12, 20)])
+@pytest.mark.parametrize("name,B,H", [("humanoidrun", 24, 20), ("humanoidtrack", 16, 20), ("humanoidstandup", 12, 20),
+                                      ("ant", 20, 20)])
 def test_pk2_general_instantiations(gpu, orc, name, B, H, monkeypatch, levers):
     levers(MBD_PK2=1)
     for k in ("MBD_NO_REWARD_CONST", "MBD_NO_NFR_CONST"):
@@ -1048,7 +1050,7 @@ def test_pk2_general_instantiations(gpu, orc, name, B, H, monkeypatch, levers):
     _rollout_bitexact(gpu, orc, name, B, H, 0.5)
 
 
-@pytest.mark.parametrize("name,B", [("humanoidrun", 8192), ("humanoidtrack", 4100), ("humanoidstandup", 4099)])
+@pytest.mark.parametrize("name,B", [("humanoidrun", 8192), ("humanoidtrack", 4100), ("humanoidstandup", 4099), ("ant", 4098)])
 def test_pk2_is_bit_identical_to_the_one_candidate_kernel_at_scale(gpu, name, B, monkeypatch, levers):
     """What a launch of more than 4096 candidates runs by default, against the one-candidate-per-lane kernel on the same
     inputs: rewards, tracked positions and the final link states of every candidate."""
@@ -1075,7 +1077,8 @@ def test_pk2_is_bit_identical_to_the_one_candidate_kernel_at_scale(gpu, name, B,
 @pytest.mark.parametrize("name,N,H,Nd,demo,pk2", [("humanoidrun", 256, 50, 12, False, None), ("humanoidrun", 96, 20, 8, False, "1"),
                                                   ("humanoidrun", 33, 12, 6, False, "1"), ("humanoidtrack", 128, 50, 8, True, None),
                                                   ("humanoidtrack", 64, 50, 6, True, "1"), ("hopper", 96, 50, 10, False, None),
-                                                  ("halfcheetah", 50, 30, 7, False, None), ("ant", 40, 20, 6, False, None)])
+                                                  ("halfcheetah", 50, 30, 7, False, None), ("ant", 40, 20, 6, False, None),
+                                                  ("ant", 64, 20, 6, False, "1")])
 def test_sweep_equals_the_plans_run_alone(gpu, name, N, H, Nd, demo, pk2, monkeypatch, levers):
     """SURVEY §8(f) N3 as ONE batched launch per diffusion step (mbd/scripts/run_mbd.py:17-39): every plan of a
     seed sweep — its own key chain and start state — comes out of mbd_sweep_run exactly as out of run_diffusion on its

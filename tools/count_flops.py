@@ -34,6 +34,7 @@ INSTANCES = {
     "humanoidrun_pk2": "pk2:1,0,7",
     "humanoidtrack_pk2": "pk2:1,3,5",
     "humanoidstandup_pk2": "pk2:5,4,7",
+    "ant_pk2": "pk2:2,6,10,1,1",
 }
 
 

@@ -8,7 +8,7 @@ import numpy as np, torch
 from mbd_hip import _capi
 from mbd_hip.envs import get_env
 H = 50
-cases = [("humanoidrun", B) for B in (1024, 2048, 4096, 8192, 16384, 32768)] + [("humanoidtrack", 8192), ("humanoidstandup", 8192)]
+cases = [("humanoidrun", B) for B in (1024, 2048, 4096, 8192, 16384, 32768)] + [("humanoidtrack", 8192), ("humanoidstandup", 8192), ("ant", 8192), ("ant", 16384)]
 if len(sys.argv) > 1:
     cases = [(a.split(":")[0], int(a.split(":")[1])) for a in sys.argv[1:]]
 for name, B in cases:
