@@ -1,0 +1,40 @@
+// mbd_planar.hip — translation unit of the planar rollouts (mbd_planar.h).  Its own file because it is built with its own
+// scheduler strategy (-mllvm -amdgpu-sched-strategy=max-ilp, __graft_entry__.build): the planar substeps are short
+// dependent chains around a few packed instructions, and the default strategy leaves 11-12 hazard s_nop per substep
+// where max-ilp leaves 4-5 (hopper 342 -> 336 instructions per substep, halfcheetah 398 -> 391, walker2d 371 -> 363:
+// a lone wavefront's time is its instruction count).  The 3-D kernels (mbd_capi.hip) keep the default.
+#define MBD_SHARED_ONLY 1
+#include "mbd_planar.h"
+#include "mbd_launch.h"
+
+namespace mbd {
+
+hipError_t launch_rollout_planar(int lps, int dpp_family, int max_col, int fl, int rk, int nfr, bool no_fl, int device,
+                                 dim3 grid, dim3 block, size_t lds, hipStream_t stream, const RolloutParams& P) {
+#define PL(...) return launch_rollout_kernel(rollout_planar_kernel<__VA_ARGS__>, device, grid, block, lds, stream, P)
+  // (... the reward kind: cartpole, hopper, walker2d, halfcheetah; and n_frames, for the values the built-in models have:
+  // NFR.  Not for halfcheetah, n_frames = 16: 2 x 8 in line measured -0.2 %, 4 x 4 with a constant trip count -0.9 % — its
+  // substep compiles to 399 / 402 instructions instead of 398)
+  if (lps == 4 && dpp_family == 2) {
+    if (max_col == 0) {
+      if (fl == 2 && rk == MBD_REW_CARTPOLE && !no_fl && nfr == 4) PL(4, 0, 1, 0, 2, MBD_REW_CARTPOLE, 4);
+      else if (fl == 2 && rk == MBD_REW_CARTPOLE && !no_fl) PL(4, 0, 1, 0, 2, MBD_REW_CARTPOLE);
+      else PL(4, 0, 1, 0);
+    }
+    else if (fl == 0 && rk == MBD_REW_HOPPER && !no_fl && nfr == 20) PL(4, 2, 1, 0, 0, MBD_REW_HOPPER, 20);
+    else if (fl == 0 && rk == MBD_REW_HOPPER && !no_fl) PL(4, 2, 1, 0, 0, MBD_REW_HOPPER);
+    else PL(4, 2, 1, 0);
+  } else if (lps == 8 && dpp_family == 1) {
+    if (fl == 0 && rk == MBD_REW_HOPPER && !no_fl && nfr == 20) PL(8, 2, 1, -3, 0, MBD_REW_HOPPER, 20);
+    else if (fl == 0 && rk == MBD_REW_HOPPER && !no_fl) PL(8, 2, 1, -3, 0, MBD_REW_HOPPER);
+    else if (fl == 1 && rk == MBD_REW_HALFCHEETAH && !no_fl) PL(8, 2, 1, -3, 1, MBD_REW_HALFCHEETAH);
+    else PL(8, 2, 1, -3);
+  }
+  else if (lps == 8 && dpp_family == 2) PL(8, 2, 1, 0);
+  else if (lps == 4) PL(4, 2, 0, 0);
+  else if (lps == 8) PL(8, 2, 0, 0);
+  else PL(16, 2, 0, 0);
+#undef PL
+}
+
+}  // namespace mbd

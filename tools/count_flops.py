@@ -43,9 +43,10 @@ def count(targs):
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "k.hip")
         kern, hdr = "rollout_kernel", "mbd_kernels.h"
+        extra = []
         if targs.startswith("planar:"):
             kern, hdr, targs = "rollout_planar_kernel", "mbd_planar.h", targs[len("planar:"):]
-        extra = []
+            extra = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]  # (the flags of its translation unit: build())
         if targs.startswith("pk2:"):
             kern, hdr, targs = "rollout_pk2_kernel", "mbd_pk2.h", targs[len("pk2:"):]
             extra = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]  # (the flags of its translation unit: build())

@@ -68,6 +68,8 @@ def analyse(kind, targs, tuned=False):
         with open(src, "w") as f:
             f.write(f'#include "{CSRC}/{hdr}"\ntemplate __global__ void mbd::{kern}<{targs}>(mbd::RolloutParams);\n')
         flags = [f for f in FLAGS if not (tuned and f == "-DMBD_PHASE_TUNING")]
+        if kind == "planar":  # (the flags of its translation unit, mbd_planar.hip: __graft_entry__.TUS)
+            flags = flags + ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
         subprocess.run(["/opt/rocm/bin/hipcc", *flags, src, "-o", asm], check=True, capture_output=True)
         lines = open(asm).read().split("\n")
         start = [i for i, l in enumerate(lines) if re.match(rf"^_ZN3mbd\d+{kern}.*:", l)][0]
