@@ -1213,3 +1213,47 @@ def test_exchange_reports_a_peer_that_never_arrives(gpu, tmp_path):
     r0 = json.load(open(os.path.join(tmp_path, "xt_rank0.json")))
     assert r0["error"] is not None and "time limit" in r0["error"], r0
     assert 1.0 < r0["seconds"] < 8.0, r0  # one limit, not four
+
+
+# ---- round 3's bench configs at their full sizes ---------------------------------------------------------------------
+def test_humanoidrun8192_full_size_step_bitexact(gpu, orc_omp):
+    """bench config humanoidrun8192 — the reference's own default N for humanoidrun (mbd_planner.py:54-60), the launch
+    the two-candidates-per-lane kernel serves by default — one whole reverse-diffusion step against the checker:
+    sampled candidates, 2.9 M pair-substeps of rollout, softmax weights, Ybar_{i-1}, bit for bit."""
+    assert gpu.debug_get("MBD_PK2") == -1  # (the library decides: more than 4096 candidates)
+    _one_step(gpu, orc_omp, "humanoidrun", 8192, 50, 100, 0.1, 1, False, i=99)
+    _one_step(gpu, orc_omp, "humanoidrun", 8192, 50, 100, 0.1, 1, False, i=7)
+
+
+def test_sweep8_full_size_equals_the_plans_run_alone(gpu):
+    """bench config sweep8 at full size: the reference's 8-seed sweep (run_mbd.py:17-39) at the metric's sizes —
+    8 plans x N=1024 x H=50 x 99 steps through ONE launch per step over 8192 candidates — against each plan's own
+    run_diffusion: mu_0ts and the final reward, bit for bit."""
+    from mbd_hip.planners.mbd_planner import Args, run_diffusion
+    from mbd_hip.scripts.run_mbd import run_concurrent
+    plans = [Args(seed=s, env_name="humanoidrun", Nsample=1024, Hsample=50, Ndiffuse=100, temp_sample=0.1,
+                  disable_recommended_params=True, not_render=True) for s in range(8)]
+    rews, mus, secs = run_concurrent(plans)
+    assert secs < 0.5
+    for a, r, mu in zip(plans, rews, mus):
+        r_seq, det = run_diffusion(a, return_details=True)
+        assert np.array_equal(mu, det["mu_0ts"]) and np.float32(r) == np.float32(r_seq), a.seed
+
+
+def test_ant_default_sweep_shape_bitexact(gpu, orc_omp):
+    """The reference's literal default sweep is ant (run_mbd.py:14; Nsample 2048): one step of such a plan against the
+    checker through the two-candidates-per-lane ant kernel (forced: a single plan of 2048 would not pick it), and a
+    3-plan sweep of them against the plans run alone."""
+    from mbd_hip.planners.mbd_planner import Args, run_diffusion
+    from mbd_hip.scripts.run_mbd import run_concurrent
+    gpu.debug_set("MBD_PK2", 1)
+    try:
+        _one_step(gpu, orc_omp, "ant", 2048, 50, 100, 0.1, 1, False, i=99)
+    finally:
+        gpu.debug_set("MBD_PK2", -1)
+    plans = [Args(seed=s, env_name="ant", Nsample=2048, Hsample=50, Ndiffuse=12, temp_sample=0.1,
+                  disable_recommended_params=True, not_render=True) for s in range(3)]
+    rews, mus, _ = run_concurrent(plans)  # 6144 candidates in one launch: two per lane by default
+    for a, r, mu in zip(plans, rews, mus):
+        r_seq, det = run_diffusion(a, return_details=True)
+        assert np.array_equal(mu, det["mu_0ts"]) and np.float32(r) == np.float32(r_seq), a.seed

@@ -10,6 +10,11 @@ sys.path.insert(0, ROOT)
 import __graft_entry__ as g  # noqa: E402
 
 name, flags = sys.argv[1], sys.argv[2:]
+while "--sched" in flags:  # --sched UNIT.hip=STRATEGY: that unit with -mllvm -amdgpu-sched-strategy=STRATEGY
+    k = flags.index("--sched")
+    unit, strat = flags[k + 1].split("=")
+    del flags[k:k + 2]
+    g.TUS = [(n, ["-mllvm", f"-amdgpu-sched-strategy={strat}"] if n == unit else f) for n, f in g.TUS]
 while "--default-sched" in flags:
     k = flags.index("--default-sched")
     unit = flags[k + 1]
