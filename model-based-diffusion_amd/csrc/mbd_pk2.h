@@ -56,11 +56,15 @@ __device__ __forceinline__ q4x2 qnormalize2(q4x2 q) {
   f2 n2 = fma2(q.w, q.w, fma2(q.x, q.x, fma2(q.y, q.y, q.z * q.z)));
   f2 e = n2 - splat(1.0f);
   f2 inv = fma2(fma2(fma2(fma2(splat(0.2734375f), e, splat(-0.3125f)), e, splat(0.375f)), e, splat(-0.5f)), e, splat(1.0f));
-  // (one cold block per half, the one-candidate kernel's pattern: both sit out of line.  As ONE block for the pair —
-  // `far0 || far1`, selects inside — it compiled to an if / else whose common side left by a TAKEN branch per substep.)
+  // (ONE cold block for the pair, with one plain `if` per half inside it: out of line, and the common path pays one
+  // compare pair, one exec save and one untaken branch.  As `far0 || far1` with selects inside it compiled to an if /
+  // else whose common side left by a TAKEN branch per substep; as two top-level ifs to twice the exec bookkeeping.)
   float i0 = inv.x, i1 = inv.y;
-  if (__builtin_expect(fabs_(e.x) > 0.05f, 0)) i0 = 1.0f / fsqrt(n2.x);
-  if (__builtin_expect(fabs_(e.y) > 0.05f, 0)) i1 = 1.0f / fsqrt(n2.y);
+  const float ax = fabs_(e.x), ay = fabs_(e.y);
+  if (__builtin_expect(fmax_(ax, ay) > 0.05f, 0)) {
+    if (ax > 0.05f) i0 = 1.0f / fsqrt(n2.x);
+    if (ay > 0.05f) i1 = 1.0f / fsqrt(n2.y);
+  }
   inv = mk2(i0, i1);
   return q4x2{q.w * inv, q.x * inv, q.y * inv, q.z * inv};
 }
