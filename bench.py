@@ -458,6 +458,29 @@ def main():
     # window, a wait that runs into its limit) is reported, it never costs the line its `value`
     other_coll = None
     if distributed and world > 1 and args.collective == "both" and not is_sweep:
+        # a canary first: one short-lived process per rank maps the peers' windows and runs a few exchanges with known
+        # values (mbd_hip.planners.exchange_canary).  Peer stores into mapped memory are what ends in an uncatchable GPU
+        # fault when a node's peer access is not what the code assumes — that must cost a canary, not this process and
+        # its RCCL measurement.  Every rank learns the worst exit status before anybody goes on.
+        import subprocess
+        import tempfile
+        rdv = os.path.join(tempfile.gettempdir(), f"mbd_canary_{os.environ.get('MASTER_PORT', '0')}_{world}")
+        try:
+            cp = subprocess.run([sys.executable, "-m", "mbd_hip.planners.exchange_canary", str(rank), str(world),
+                                 str(local_rank), rdv], cwd=os.path.join(ROOT, "model-based-diffusion_amd"),
+                                capture_output=True, text=True, timeout=240)
+            canary_rc, canary_err = cp.returncode, cp.stderr[-300:]
+        except Exception as e:  # noqa: BLE001
+            canary_rc, canary_err = 99, f"{type(e).__name__}: {e}"
+        worst = torch.tensor([abs(canary_rc)], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            import shutil
+            shutil.rmtree(rdv, ignore_errors=True)
+        if int(worst.item()) != 0:
+            other_coll = {"collective": "p2p", "error": f"canary failed (worst exit status {int(worst.item())}; rank {rank}: "
+                                                            f"{canary_rc} {canary_err.strip()[-200:]})"}
+    if distributed and world > 1 and args.collective == "both" and not is_sweep and other_coll is None:
         try:
             oc = measure(*runs[args.scaling], collective="p2p")
             other_coll = {"collective": "p2p (mbd_exchange_*: hipIpc-mapped windows, peer stores + epoch flags)",
