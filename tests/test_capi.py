@@ -186,3 +186,31 @@ def test_c_abi_argument_errors_without_a_device(lib):
     n = C.c_int(-1)
     assert lib.mbd_device_count(C.byref(n)) == 0 and n.value >= 0
     assert lib.mbd_version() >= 1
+
+
+def test_round3_entry_points_fail_loudly_without_a_device_and_levers_work_on_the_host(lib):
+    """The in-library exchange and the sweeps have no CPU path either: without a GPU their constructors return
+    MBD_ERR_NO_DEVICE (argument errors first).  The debug levers are host state: the table is seeded from the
+    environment once, mbd_debug_set / get work without a device, unknown names are rejected."""
+    from mbd_hip import _capi
+    h = C.c_void_p()
+    assert lib.mbd_exchange_create(0, 0, 1, 1, 8, None) == _capi.MBD_ERR_INVALID
+    assert lib.mbd_sweep_create(None, None, 2, None, C.byref(h)) == _capi.MBD_ERR_INVALID
+    if _capi.device_count() == 0:
+        assert lib.mbd_exchange_create(0, 0, 2, 1, 8, C.byref(h)) == _capi.MBD_ERR_NO_DEVICE
+        assert b"no CPU fallback" in lib.mbd_last_error()
+    assert set(_capi.LEVERS) >= {"MBD_PK2", "MBD_NO_DPP", "MBD_NO_LAZY"}
+    for name in _capi.LEVERS:
+        before = _capi.debug_get(name)
+        _capi.debug_set(name, 1)
+        assert _capi.debug_get(name) == 1
+        _capi.debug_set(name, before)
+    with pytest.raises(_capi.MbdError):
+        _capi.debug_set("MBD_NO_SUCH_LEVER", 1)
+    # the debug header declares exactly what the library exports beside the product ABI
+    import os, re
+    from conftest import ROOT
+    text = open(os.path.join(ROOT, "include", "mbd_hip_debug.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    for n in sorted(set(re.findall(r"\b(mbd_debug_[a-z0-9_]+)\s*\(", text))):
+        assert hasattr(lib, n), n
