@@ -252,6 +252,9 @@ def main():
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-final-reward", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="default config on one GPU: skip the short extra measurements (the reference's default humanoidrun "
+                         "size N=8192, its 8-seed sweep) that ride in the line under `extras`")
     ap.add_argument("--collective", choices=("torch", "p2p", "both"), default="both",
                     help="N > 1: the step's exchange — torch (all_gather_into_tensor: RCCL over xGMI), p2p (the in-library "
                          "windows, mbd_exchange_*), both (torch is `value`, p2p is measured after it and reported beside)")
@@ -299,14 +302,15 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     rows = 2 if DEMO else 1
 
-    def measure_sweep():
+    def measure_sweep(P=None, steps=None, warmup=None):
         """config sweep8: K lockstep diffusion steps of P plans (mbd_sweep_run with Ndiffuse = K + 1; W + 1 for the
         warm-up run).  No per-step host read: the reference's sweep prints nothing per step either (not_render runs of
         run_diffusion keep their progress bar, but the sweep's measure is the time of whole runs)."""
         from mbd_hip.planners.mbd_planner import Sweep
-        P = cfg["plans"]
+        P = P or cfg["plans"]
+        steps, warmup = steps or args.steps, (args.warmup if warmup is None else warmup)
         out = None
-        for nd, timed in ((args.warmup + 1, False), (args.steps + 1, True)):
+        for nd, timed in ((warmup + 1, False), (steps + 1, True)):
             a = Args(seed=0, env_name=ENV, Nsample=N_CFG, Hsample=H, Ndiffuse=max(nd, 2), temp_sample=TEMP,
                      disable_recommended_params=True, not_render=True)
             sw = Sweep(env, a, P)
@@ -525,6 +529,35 @@ def main():
             final["equals_one_gpu_bitwise"] = bool(np.array_equal(np.float32(rews), np.float32(single)))
             final["rew_final_one_gpu"] = single
 
+    # Short extra measurements that ride in the default line (one GPU, config `metric`): what round 3 built for the sizes
+    # above the metric's — the reference's own default humanoidrun plan (N = 8192, mbd_planner.py:54-60) and its 8-seed
+    # sweep (scripts/run_mbd.py:17-39) — so that the driver's record of this command holds them too.  ~3 s.
+    extras = None
+    if rank == 0 and not distributed and args.config == "metric" and not args.no_extras and not os.environ.get("MBD_BENCH_N"):
+        extras = {}
+        try:
+            a = Args(seed=0, env_name=ENV, Nsample=8192, Hsample=H, Ndiffuse=41, temp_sample=TEMP,
+                     disable_recommended_params=True, not_render=True)
+            rng0, rng_reset = _capi.prng_split(_capi.prng_key(0), 2)
+            big = Plan(env, a)
+            big.set_state0(env.reset(rng_reset))
+            big.run(_capi.prng_split(rng0, 2)[0])            # warm-up
+            big.enable_timing(True)
+            _, _, _, secs = big.run(_capi.prng_split(rng0, 2)[0])
+            big.enable_timing(False)
+            kms, _ = big.kernel_time()
+            big.close()
+            extras["humanoidrun8192"] = {"workload": "humanoidrun N=8192 H=50, 40 steps of mbd_plan_run (no per-step host read)",
+                                         "steps_per_sec": 40 / secs, "kernel_avg_ms": kms, "_candidates": 8192,
+                                         "kernel": CONFIGS["humanoidrun8192"]["kernel"]}
+            cfg_sw = dict(CONFIGS["sweep8"])
+            sw_secs, sw_kms, _ = measure_sweep(P=cfg_sw["plans"], steps=40, warmup=5)
+            extras["sweep8"] = {"workload": "8 plans x humanoidrun N=1024 H=50 in lockstep, 40 steps of mbd_sweep_run",
+                                "plan_steps_per_sec": cfg_sw["plans"] * 40 / sw_secs, "kernel_avg_ms": sw_kms,
+                                "_candidates": 8192, "kernel": cfg_sw["kernel"]}
+        except Exception as e:  # noqa: BLE001 — extras never cost the line its value
+            extras["error"] = f"{type(e).__name__}: {e}"
+
     if rank == 0:
         def rate(mode, which):
             (el_s, _, _), (el_a, _, _) = res[mode]
@@ -602,6 +635,13 @@ def main():
             if live:
                 fsub, fsub_src = live, "oracle/count_ops.cc (this run)"
         out["valu"] = valu_view(cfg, N_local * cfg.get("plans", 1), kern_ms, n_frames, fsub, fsub_src)
+        if extras is not None:
+            for k, e in extras.items():  # (the VALU view of the extra workloads needs the op count of this line)
+                if fsub and e.get("kernel_avg_ms"):
+                    e["valu_algorithmic_frac"] = (float(fsub["flops"]) * e.pop("_candidates") * H * n_frames /
+                                                  (e["kernel_avg_ms"] * 1e-3) / 1e12 / VALU_PEAK_TF)
+                e.pop("_candidates", None)
+            out["extras"] = extras
         print(json.dumps(out))
     if distributed:
         dist.barrier()
