@@ -1257,3 +1257,28 @@ def test_ant_default_sweep_shape_bitexact(gpu, orc_omp):
     for a, r, mu in zip(plans, rews, mus):
         r_seq, det = run_diffusion(a, return_details=True)
         assert np.array_equal(mu, det["mu_0ts"]) and np.float32(r) == np.float32(r_seq), a.seed
+
+
+def test_c_caller_without_python(gpu, tmp_path):
+    """examples/mbd_run.c — run_diffusion and the seed sweep from plain C through include/mbd_hip.h (envs by name, no
+    Python, no MJCF compiler) — compiled with gcc against the in-tree library and run: every plan's final reward equals
+    the Python shim's run_diffusion for the same seed bit for bit (%.9g round-trips a float32), alone and in the sweep."""
+    import re, shutil, subprocess
+    from conftest import ROOT
+    from mbd_hip.planners.mbd_planner import Args, run_diffusion
+    if shutil.which("gcc") is None:
+        pytest.skip("no gcc on this box")
+    exe = str(tmp_path / "mbd_run")
+    libdir = os.path.join(ROOT, "model-based-diffusion_amd", "lib")
+    subprocess.run(["gcc", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "examples", "mbd_run.c"),
+                    "-o", exe, "-L", libdir, "-lmbd_hip", f"-Wl,-rpath,{libdir}", "-lm"], check=True)
+    out = subprocess.run([exe, "humanoidrun", "256", "20", "9", "0.1", "3"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr
+    alone = {int(m.group(1)): np.float32(m.group(2)) for m in re.finditer(r"^seed (\d+) rew_final (\S+)", out.stdout, re.M)}
+    swept = {int(m.group(1)): np.float32(m.group(2)) for m in re.finditer(r"^sweep seed (\d+) rew_final (\S+)", out.stdout, re.M)}
+    assert sorted(alone) == [0, 1, 2] and sorted(swept) == [0, 1, 2]
+    for seed in range(3):
+        a = Args(seed=seed, env_name="humanoidrun", Nsample=256, Hsample=20, Ndiffuse=9, temp_sample=0.1,
+                 disable_recommended_params=True, not_render=True)
+        r = np.float32(run_diffusion(a))
+        assert alone[seed] == r and swept[seed] == r, (seed, alone[seed], swept[seed], r)
