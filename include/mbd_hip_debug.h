@@ -9,7 +9,8 @@ extern "C" {
 #endif
 /* One process-wide table of integer levers, initialised ONCE from the environment variables of the same names
  * (MBD_NO_DPP, MBD_NO_NFR_CONST, MBD_NO_REWARD_CONST, MBD_NO_PLANAR_FLAGS, MBD_NO_FAST_SLIDES, MBD_NO_FUSED_NOISE,
- * MBD_NO_LAZY, MBD_NO_PREFETCH, MBD_NO_AUX, MBD_WMEAN_SPLIT, MBD_NO_FUSED_SCORE, MBD_PK2, MBD_WPB, MBD_LDS_RESERVE);
+ * MBD_NO_LAZY, MBD_NO_PREFETCH, MBD_NO_AUX, MBD_WMEAN_SPLIT, MBD_NO_FUSED_SCORE, MBD_PK2, MBD_WPB, MBD_LDS_RESERVE,
+ * MBD_NO_HELPERS);
  * -1 = not set: the library decides.  The launch paths read the table, never the environment. */
 int mbd_debug_set(const char* name, int value);
 int mbd_debug_get(const char* name, int* value_out);

@@ -123,7 +123,7 @@ def load() -> C.CDLL:
 
 LEVERS = ("MBD_NO_DPP", "MBD_NO_NFR_CONST", "MBD_NO_REWARD_CONST", "MBD_NO_PLANAR_FLAGS", "MBD_NO_FAST_SLIDES",
           "MBD_NO_FUSED_NOISE", "MBD_NO_LAZY", "MBD_NO_PREFETCH", "MBD_NO_AUX", "MBD_WMEAN_SPLIT", "MBD_NO_FUSED_SCORE",
-          "MBD_PK2", "MBD_WPB", "MBD_LDS_RESERVE")
+          "MBD_PK2", "MBD_WPB", "MBD_LDS_RESERVE", "MBD_NO_HELPERS")
 
 
 def debug_set(name: str, value: int) -> None:

@@ -1282,3 +1282,19 @@ def test_c_caller_without_python(gpu, tmp_path):
                  disable_recommended_params=True, not_render=True)
         r = np.float32(run_diffusion(a))
         assert alone[seed] == r and swept[seed] == r, (seed, alone[seed], swept[seed], r)
+
+
+@pytest.mark.parametrize("helpers", [True, False])
+def test_humanoidstandup_helper_lanes(gpu, orc, helpers, levers):
+    """humanoidstandup's torso carries five sphere colliders.  By default its colliders 2..4 run stage (4) — a Jacobi
+    solve: every contact sees the pose of the stage's start — on two of the candidate's five idle lanes, which ride on
+    the torso's pose and hand impulse, rotation, contact point, multiplier and flag back; the torso adds them in
+    collider order with the loop's own operations (HELP instantiations: 1726 -> 1345 instructions per substep).  The
+    lever MBD_NO_HELPERS=1 keeps every collider on the torso's lane.  Both against the checker, bit for bit: rollouts
+    with saturated actions (all fifteen colliders touch the floor while the humanoid lies down) and a planning step."""
+    levers(MBD_NO_HELPERS=0 if helpers else 1)
+    _rollout_bitexact(gpu, orc, "humanoidstandup", 52, 50, 0.9)
+    _rollout_bitexact(gpu, orc, "humanoidstandup", 3, 7, 0.2)
+    _one_step(gpu, orc, "humanoidstandup", 96, 20, 30, 0.1, 1, False, i=29)
+    levers(MBD_NO_REWARD_CONST=1, MBD_NO_NFR_CONST=1)   # the general instantiation of either form
+    _rollout_bitexact(gpu, orc, "humanoidstandup", 12, 20, 0.5)

@@ -19,6 +19,7 @@ INSTANCES = {
     "humanoidrun": "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,0,7",
     "humanoidtrack": "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,3,5",
     "humanoidstandup": "16,true,false,3,5,1,-4,-6,0,false,true,3,false,false,4,7",
+    "humanoidstandup_help": "16,true,false,3,5,1,-4,-6,0,false,true,3,false,false,4,7,true",
     "ant": "16,true,false,4,2,1,-2,-4,-6,false,false,3,false,false,6,10",
     "halfcheetah": "8,true,true,4,2,1,-3,0,0,false,false,2,true",
     "walker2d": "8,false,true,4,2,1,-3,0,0,true,false,2,true,true",
@@ -108,7 +109,7 @@ def count(targs):
     unroll = 4 if kern == "rollout_planar_kernel" else 2  # (substeps per iteration of the substep loop)
     if kern == "rollout_planar_kernel" and len(targs.split(",")) >= 7 and int(targs.split(",")[6]) > 0:
         unroll = int(targs.split(",")[6]) // 2
-    if kern == "rollout_kernel" and len(targs.split(",")) >= 16 and int(targs.split(",")[15]) > 0:
+    if kern == "rollout_kernel" and len(targs.split(",")) >= 16 and targs.split(",")[15].strip().isdigit() and int(targs.split(",")[15]) > 0:
         unroll = int(targs.split(",")[15]) // 2
     if kern == "rollout_pk2_kernel":
         unroll = int(targs.split(",")[2]) // 2 if int(targs.split(",")[2]) > 1 else 2
