@@ -1063,8 +1063,8 @@ def test_pk2_is_bit_identical_to_the_one_candidate_kernel_at_scale(gpu, name, B,
     want = env.xref is not None
     res = {}
     for k in ("0", "auto"):
-        if k == "auto":
-            levers(MBD_PK2=-1)
+        if k == "auto":  # (humanoidstandup keeps one candidate per lane by default — helper lanes: forced here)
+            levers(MBD_PK2=1 if name == "humanoidstandup" else -1)
         else:
             levers(MBD_PK2=k)
         out = env.rollout(st, us, want_xpos=want, want_final=True)
