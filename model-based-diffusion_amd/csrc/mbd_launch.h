@@ -39,6 +39,10 @@ inline hipError_t launch_rollout_kernel(K kernel, int device, dim3 grid, dim3 bl
 // the two-candidates-per-lane rollouts of the humanoid family (mbd_pk2.h; their own translation unit, mbd_pk2.hip, built
 // with the scheduler strategy that keeps dependent packed instructions apart).  hipErrorInvalidValue: no such instantiation.
 // wpe: 2 asks for the instantiation whose registers leave room for two wavefronts per SIMD (where there is one).
+// the 3-D instantiations the built-in humanoids and ant run (their own translation unit, mbd_hot3d.hip): which = 0 humanoid
+// with one collider per link, 1 / 2 up to five with / without helper lanes, 3 ant; rk = -1, nfr = 0: the run-time forms
+hipError_t launch_rollout_hot3d(int which, int rk, int nfr, int device, dim3 grid, dim3 block, size_t lds, hipStream_t stream,
+                                const RolloutParams& P);
 // the planar rollouts (mbd_planar.h; their own translation unit, mbd_planar.hip): lps lanes per candidate, the env's DPP
 // family, colliders per link, fl = the model's switches (1 springs | 2 slide limits | 4 elasticity), reward kind, n_frames
 // (0: run-time), no_fl: the general instantiation (lever MBD_NO_PLANAR_FLAGS)

@@ -44,7 +44,10 @@ def count(targs):
     with tempfile.TemporaryDirectory() as td:
         src = os.path.join(td, "k.hip")
         kern, hdr = "rollout_kernel", "mbd_kernels.h"
-        extra = []
+        # (the flags of the translation unit an instantiation is built in, __graft_entry__.TUS: the DPP instantiations of
+        # the humanoids and ant are mbd_hot3d.hip's)
+        hot = targs.startswith(("16,true,false,3,1,1,-4,-6", "16,true,false,3,5,1,-4,-6", "16,true,false,4,2,1,-2,-4,-6,false,false"))
+        extra = ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"] if hot else []
         if targs.startswith("planar:"):
             kern, hdr, targs = "rollout_planar_kernel", "mbd_planar.h", targs[len("planar:"):]
             extra = ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]  # (the flags of its translation unit: build())

@@ -70,6 +70,8 @@ def analyse(kind, targs, tuned=False):
         flags = [f for f in FLAGS if not (tuned and f == "-DMBD_PHASE_TUNING")]
         if kind == "planar":  # (the flags of its translation unit, mbd_planar.hip: __graft_entry__.TUS)
             flags = flags + ["-mllvm", "-amdgpu-sched-strategy=max-ilp"]
+        else:  # (the built-in humanoids' instantiations: mbd_hot3d.hip)
+            flags = flags + ["-mllvm", "-amdgpu-sched-strategy=iterative-ilp"]
         subprocess.run(["/opt/rocm/bin/hipcc", *flags, src, "-o", asm], check=True, capture_output=True)
         lines = open(asm).read().split("\n")
         start = [i for i, l in enumerate(lines) if re.match(rf"^_ZN3mbd\d+{kern}.*:", l)][0]
