@@ -216,6 +216,7 @@ __device__ __forceinline__ void dpp_fetch_p(v3x2 p, q4x2 r, const float (&m)[4],
 template <int MAXCOL, int RK = -1, int NFR = 0, int WPE = 1, int FAM = 0>
 __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) {
   constexpr bool MULTI = FAM == 0;
+  rollout_progress(P);
   if ((int)blockIdx.x >= P.roll_blocks) {  // the next step's normals, on CUs the rollout leaves idle
     noise_blocks(P);
     return;

@@ -78,6 +78,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   static_assert(NFR % 2 == 0, "NFR: two iterations of NFR / 2");
   constexpr bool DPP = D0 != 0;
   constexpr int NSLOT = DPP ? (D1 != 0 ? 2 : 1) : kMaxChildren;
+  rollout_progress(P);
   if ((int)blockIdx.x >= P.roll_blocks) {  // the next step's normals, on CUs the rollout leaves idle (mbd_kernels.h)
     noise_blocks(P);
     return;

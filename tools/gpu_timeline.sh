@@ -17,13 +17,15 @@ tabs=[r[0] for r in c.execute("select name from sqlite_master where type in ('ta
 v=[t for t in tabs if t.startswith('kernels')] or [t for t in tabs if 'kernel' in t]
 rows=list(c.execute("select name, start, end from %s order by start" % v[0]))
 print("$m", len(rows), "dispatches")
-# async half of the run = the last third; print 14 dispatches from there
-k0=len(rows)-40
+# async half of the run = the last third; print 14 dispatches from there (WIN=sync: from the first third, the leg with
+# the per-step host read)
+import os
+k0=len(rows)//4 if os.environ.get("WIN")=="sync" else len(rows)-40
 prev=None
 gaps={}
 for i,(n,s,e) in enumerate(rows):
     short=n.split('(')[0].replace('void ','').replace('mbd::','')[:22]
-    if prev is not None and i>=len(rows)-100:
+    if prev is not None and (i>=len(rows)-100 if os.environ.get("WIN")!="sync" else (len(rows)//6<=i<len(rows)//3)):
         gaps.setdefault((prevname,short),[]).append((s-prev)/1000.0)
     if i>=k0 and i<k0+14:
         print("  %-22s start %+10.2f us  dur %8.2f  gap %6.2f" % (short,(s-rows[k0][1])/1000.0,(e-s)/1000.0,(s-prev)/1000.0 if prev else 0))
