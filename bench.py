@@ -303,36 +303,37 @@ def main():
     rows = 2 if DEMO else 1
 
     def measure_sweep(P=None, steps=None, warmup=None):
-        """config sweep8: K lockstep diffusion steps of P plans (mbd_sweep_run with Ndiffuse = K + 1; W + 1 for the
-        warm-up run).  No per-step host read: the reference's sweep prints nothing per step either (not_render runs of
+        """config sweep8: K lockstep diffusion steps of P plans (mbd_sweep_run with Ndiffuse = K + 1).  No per-step host read: the reference's sweep prints nothing per step either (not_render runs of
         run_diffusion keep their progress bar, but the sweep's measure is the time of whole runs)."""
         from mbd_hip.planners.mbd_planner import Sweep
         P = P or cfg["plans"]
         steps, warmup = steps or args.steps, (args.warmup if warmup is None else warmup)
-        # (the kernel-time leg is a run of its own: two event records around every rollout launch cost a lockstep step
-        # ~7 us, 0.7 % — the value leg runs without them)
-        out = None
-        secs_value = None
-        for nd, timed in ((warmup + 1, False), (steps + 1, False), (steps + 1, True)):
-            a = Args(seed=0, env_name=ENV, Nsample=N_CFG, Hsample=H, Ndiffuse=max(nd, 2), temp_sample=TEMP,
-                     disable_recommended_params=True, not_render=True)
-            sw = Sweep(env, a, P)
-            keys = []
-            for k in range(P):
-                rng, rng_reset = _capi.prng_split(_capi.prng_key(k), 2)
-                sw.set_state0(k, env.reset(rng_reset))
-                keys.append(_capi.prng_split(rng, 2)[0])
-            sw.kernel_time(enable=timed)
-            torch.cuda.synchronize(dev)
-            _, _, _, secs = sw.run(np.array(keys, np.uint32))
-            torch.cuda.synchronize(dev)
-            if timed:
-                kern_ms, kern_n = sw.kernel_time(enable=False)
-                out = (secs_value, kern_ms, kern_n)
-            elif nd == steps + 1:
-                secs_value = secs
-            sw.close()
-        return out
+        # ONE sweep object (its buffers are touched by the warm-up, not by the timed run): a warm-up run of all its steps
+        # (K >= W untimed steps), the timed run of the same K steps, and a third run with HIP events around the rollout
+        # launches for the kernel time (two event records cost a lockstep step ~7 us, 0.7 % — the value run has none)
+        nd = steps + 1  # (the timed run is exactly K steps)
+        a = Args(seed=0, env_name=ENV, Nsample=N_CFG, Hsample=H, Ndiffuse=max(nd, 2), temp_sample=TEMP,
+                 disable_recommended_params=True, not_render=True)
+        sw = Sweep(env, a, P)
+        keys = []
+        for k in range(P):
+            rng, rng_reset = _capi.prng_split(_capi.prng_key(k), 2)
+            sw.set_state0(k, env.reset(rng_reset))
+            keys.append(_capi.prng_split(rng, 2)[0])
+        keys = np.array(keys, np.uint32)
+        done = 0
+        while done < max(warmup, 1):  # warm-up: whole runs until at least W steps have been taken
+            sw.run(keys)
+            done += steps
+        torch.cuda.synchronize(dev)
+        _, _, _, secs_value = sw.run(keys)
+        torch.cuda.synchronize(dev)
+        sw.kernel_time(enable=True)
+        sw.run(keys)
+        torch.cuda.synchronize(dev)
+        kern_ms, kern_n = sw.kernel_time(enable=False)
+        sw.close()
+        return secs_value, kern_ms, kern_n
 
     def measure(N_total, N_local, collective="torch"):
         """K synced + K async steps of a plan with N_total candidates of which this rank owns N_local."""

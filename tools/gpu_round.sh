@@ -12,7 +12,7 @@ fi
 if [[ " $what " == *" bench "* ]]; then
   python bench.py --steps 60 --warmup 10 2>$OUT/bench_err.log | tail -1 > $OUT/bench_${TAG}_metric.json; cat $OUT/bench_${TAG}_metric.json
   for c in hopper512 halfcheetah1024 humanoidrun4096 humanoidtrack2048demo car2d humanoidrun8192 sweep8; do
-    python bench.py --config $c --steps 40 --warmup 5 2>>$OUT/bench_err.log | tail -1 > $OUT/bench_${TAG}_$c.json; cat $OUT/bench_${TAG}_$c.json
+    python bench.py --config $c --steps 100 --warmup 10 2>>$OUT/bench_err.log | tail -1 > $OUT/bench_${TAG}_$c.json; cat $OUT/bench_${TAG}_$c.json
   done
 fi
 if [[ " $what " == *" prof "* ]]; then
