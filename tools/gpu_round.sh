@@ -27,6 +27,8 @@ if [[ " $what " == *" prof "* ]]; then
     rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC --kernel-trace -d $OUT/prof_${c}_wait -o ${TAG} -- $B --steps 20 --warmup 2 > $OUT/prof_${c}_wait.log 2>&1
     # summarise here: the databases are too big to travel back (gpurun_out is capped at 64 MiB)
     mkdir -p $OUT/profiles
+    # (the PMC summary is one file keyed by config: start from the repo's, so that configs not profiled in this call stay)
+    [ -f $OUT/profiles/${TAG}_pmc.json ] || cp $R/profiles/${TAG}_pmc.json $OUT/profiles/ 2>/dev/null
     python $R/tools/rocprof_summary.py --out $OUT/profiles ${TAG} --config $c $OUT/prof_${c}_stats/${TAG}_results.db $OUT/prof_${c}_sq/${TAG}_results.db $OUT/prof_${c}_fetch/${TAG}_results.db $OUT/prof_${c}_write/${TAG}_results.db $OUT/prof_${c}_wait/${TAG}_results.db | tail -1 | cut -c1-400
     rm -rf $OUT/prof_${c}_stats $OUT/prof_${c}_sq $OUT/prof_${c}_fetch $OUT/prof_${c}_write $OUT/prof_${c}_wait
   done
