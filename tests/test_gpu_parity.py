@@ -1298,3 +1298,53 @@ def test_humanoidstandup_helper_lanes(gpu, orc, helpers, levers):
     _one_step(gpu, orc, "humanoidstandup", 96, 20, 30, 0.1, 1, False, i=29)
     levers(MBD_NO_REWARD_CONST=1, MBD_NO_NFR_CONST=1)   # the general instantiation of either form
     _rollout_bitexact(gpu, orc, "humanoidstandup", 12, 20, 0.5)
+
+
+@pytest.mark.parametrize("mode", ["host_ahead", "host_in_step", "other_stream"])
+def test_noise_ring_orderings_are_bit_identical(gpu, mode, levers):
+    """Plans whose rollout fills the chip keep their normals in a ring of three buffers filled on a second stream (forced
+    here on a small plan by MBD_NO_FUSED_NOISE): a caller that never waits (held one step behind the device through the
+    progress word), one that synchronises after every step (the mark behind the weighted mean), and one that alternates
+    the stream of its calls must all equal mbd_plan_run's own loop — Ybars, mean rewards, final reward — over enough steps
+    for the ring to wrap several times."""
+    levers(MBD_NO_FUSED_NOISE=1)
+    import torch
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.mbd_planner import Args, Plan
+    N, H, Nd = 1024, 20, 14
+    env = get_env("humanoidrun")
+    args = Args(env_name="humanoidrun", Nsample=N, Hsample=H, Ndiffuse=Nd, temp_sample=0.1,
+                disable_recommended_params=True, not_render=True)
+    st = env.reset(gpu.prng_key(2))
+    key = gpu.prng_key(6)
+    p1 = Plan(env, args)
+    p1.set_state0(st)
+    mu1, rm1, rf1, _ = p1.run(key)
+    p1.close()
+    p2 = Plan(env, args)
+    p2.set_state0(st)
+    HNu = H * 17
+    side = torch.cuda.Stream()
+    bufs = [torch.zeros(HNu, device="cuda") for _ in range(Nd)]
+    rms = torch.zeros(Nd, device="cuda")
+    loc = torch.zeros(N, device="cuda")
+    torch.cuda.synchronize()
+    rng = np.asarray(key, np.uint32)
+    impl = int(p2.cfg.prng_impl)
+    keys = gpu.prng_split(rng, 2, impl)
+    for k, i in enumerate(range(Nd - 1, 0, -1)):
+        rng, ks = keys[0], gpu.key_array(keys[1])
+        keys = gpu.prng_split(rng, 2, impl)
+        if i > 1:
+            gpu.check(p2.lib.mbd_plan_prefetch_noise(p2.h, gpu.key_array(keys[1]), None))
+        stream = side.cuda_stream if (mode == "other_stream" and k % 2) else None
+        gpu.check(p2.lib.mbd_plan_sample_rollout(p2.h, i, ks, bufs[k].data_ptr(), loc.data_ptr(), None, stream))
+        gpu.check(p2.lib.mbd_plan_score_update(p2.h, i, ks, bufs[k].data_ptr(), loc.data_ptr(), None, bufs[k + 1].data_ptr(),
+                                               rms[k:].data_ptr(), stream))
+        if mode == "host_in_step":
+            torch.cuda.synchronize()
+    torch.cuda.synchronize()
+    mus = np.stack([b.cpu().numpy().reshape(H, 17) for b in bufs[1:]])
+    assert np.array_equal(mus, mu1) and np.array_equal(rms.cpu().numpy()[:Nd - 1], rm1), mode
+    assert p2.eval(mu1[-1]) == rf1
+    p2.close()
