@@ -22,7 +22,7 @@ hipError_t launch_rollout_hot3d(int which, int rk, int nfr, int device, dim3 gri
     HOT(16, true, false, 3, 1, D0, D1, D2, 0, false, true);
   }
   if (which == 1) {  // humanoidstandup: the torso's colliders 2..4 run stage (4) on two of the candidate's idle lanes (HELP)
-    if (rk == MBD_REW_HUMANOIDSTANDUP && nfr == 7) HOT(16, true, false, 3, 5, D0, D1, D2, 0, false, true, 3, false, false, MBD_REW_HUMANOIDSTANDUP, 7, true);
+    if (rk == MBD_REW_HUMANOIDSTANDUP && nfr == 7) HOT(16, true, false, 3, 5, D0, D1, D2, 0, false, true, 3, false, false, MBD_REW_HUMANOIDSTANDUP, 7, true, true);
     HOT(16, true, false, 3, 5, D0, D1, D2, 0, false, true, 3, false, false, -1, 0, true);
   }
   if (which == 2) {
@@ -30,7 +30,7 @@ hipError_t launch_rollout_hot3d(int which, int rk, int nfr, int device, dim3 gri
     HOT(16, true, false, 3, 5, D0, D1, D2, 0, false, true);
   }
   if (which == 3) {  // ant (the reference's default env_name): reward kind and n_frames compiled in, like the humanoids
-    if (rk == MBD_REW_ANT && nfr == 10) HOT(16, true, false, 4, 2, 1, -2, -4, -6, false, false, 3, false, false, MBD_REW_ANT, 10);
+    if (rk == MBD_REW_ANT && nfr == 10) HOT(16, true, false, 4, 2, 1, -2, -4, -6, false, false, 3, false, false, MBD_REW_ANT, 10, false, true);
     HOT(16, true, false, 4, 2, 1, -2, -4, -6, false, false);
   }
 #undef HOT

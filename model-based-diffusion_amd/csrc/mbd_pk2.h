@@ -496,6 +496,11 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
       // ---- (6) collisions.resolve_velocity --------------------------------------------------------------
 #pragma unroll
       for (int j = 0; j < MAXCOL; ++j) {
+        // (SKIP6 of mbd_kernels.h: ant's second collider — the ankle end of a lower leg — rarely touches; the slot's whole
+        // effect is two selects on its `active` flags, so skipping it when no lane of the wavefront has one set is exact)
+        if constexpr (FAM == 1) {
+          if (j > 0 && __builtin_expect(__builtin_amdgcn_ballot_w64(con_act[j].x || con_act[j].y) == 0ull, 1)) continue;
+        }
         const v3x2 rc = sub2(con_pos[j], p);
         const v3x2 vpt = add2(v, cross2(w, rc));
         f2 vn_prev = splat(0.0f);

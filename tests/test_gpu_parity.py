@@ -1348,3 +1348,43 @@ def test_noise_ring_orderings_are_bit_identical(gpu, mode, levers):
     assert np.array_equal(mus, mu1) and np.array_equal(rms.cpu().numpy()[:Nd - 1], rm1), mode
     assert p2.eval(mu1[-1]) == rf1
     p2.close()
+
+
+@pytest.mark.parametrize("pk2", [0, 1])
+def test_ant_second_collider_skip_is_exact(gpu, orc, pk2, levers):
+    """ant's rollout instantiations skip stage (6) of a link's SECOND collider (the ankle end of a lower leg's capsule)
+    when no lane of the wavefront has it in contact (SKIP6, mbd_kernels.h / mbd_pk2.h).  From the standing start that
+    slot is idle; here the ant is dropped flat on its belly with its legs spread, so that both ends of every lower leg
+    touch the floor in some candidates and not in others: the kernel must equal the checker bit for bit through both
+    sides of the test, one and two candidates per lane."""
+    from mbd_hip.envs import get_env
+    levers(MBD_PK2=pk2)
+    env = get_env("ant")
+    oe = _oenv(orc, env)
+    m = env.sys
+    q = np.array(m.init_q, np.float32).copy()
+    q[2] = 0.07                      # torso 7 cm above the floor (standing: 0.55)
+    q[7:] = 0.0                      # hips and ankles at zero: the lower legs level with the floor (outside the ankles'
+                                     # range: the limit corrections then lift the ankle ends at candidate-dependent times)
+    s0 = orc.forward(m.to_struct(), q, np.zeros(m.qd_size(), np.float32))
+    # (the premise: in this pose the ankle-end spheres — every second collider — are at or below the floor)
+    f = m.fields
+    col_link, col_pos, col_rad = np.asarray(f["col_link"]), np.asarray(f["col_pos"], np.float32), np.asarray(f["col_radius"], np.float32)
+    st = np.asarray(s0, np.float32).reshape(-1, 13)
+    def rot(qw, v):
+        w, x, y, z = qw
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                      [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                      [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        return R @ v
+    low = [st[l, 0:3][2] + rot(st[l, 3:7], col_pos[k])[2] - col_rad[k] for k, l in enumerate(col_link)]
+    assert min(low[1::2]) < 0.02, low
+    B, H = 96, 30
+    rng = np.random.default_rng(17)
+    us = np.clip(rng.normal(size=(B, H, env.action_size)) * 0.8, -1.0, 1.0).astype(np.float32)
+    from mbd_hip.envs.base import State
+    state = env.reset(gpu.prng_key(3))
+    state = state.replace(pipeline_state=np.asarray(s0, np.float32)) if hasattr(state, "replace") else State(np.asarray(s0, np.float32), state.obs, state.reward, state.done)
+    got = env.rollout(state, us).cpu().numpy()
+    ref = oe.rollout(np.asarray(s0, np.float32), us)
+    assert np.isfinite(got).all() and np.array_equal(got, ref), np.abs(got - ref).max()

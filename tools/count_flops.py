@@ -19,8 +19,8 @@ INSTANCES = {
     "humanoidrun": "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,0,7",
     "humanoidtrack": "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,3,5",
     "humanoidstandup": "16,true,false,3,5,1,-4,-6,0,false,true,3,false,false,4,7",
-    "humanoidstandup_help": "16,true,false,3,5,1,-4,-6,0,false,true,3,false,false,4,7,true",
-    "ant": "16,true,false,4,2,1,-2,-4,-6,false,false,3,false,false,6,10",
+    "humanoidstandup_help": "16,true,false,3,5,1,-4,-6,0,false,true,3,false,false,4,7,true,true",
+    "ant": "16,true,false,4,2,1,-2,-4,-6,false,false,3,false,false,6,10,false,true",
     "halfcheetah": "8,true,true,4,2,1,-3,0,0,false,false,2,true",
     "walker2d": "8,false,true,4,2,1,-3,0,0,true,false,2,true,true",
     "hopper": "4,false,true,4,2,1,0,0,0,true,false,2,true,true",
