@@ -23,7 +23,9 @@ step k+1 before it holds step k's mean reward.  `value` is measured with the per
                                                           mbd_planner.py:54-60; the two-candidates-per-lane kernel)
    sweep8            the reference's 8-seed sweep (mbd/scripts/run_mbd.py:17-39) at the metric's sizes: 8 plans x
                      N=1024 in lockstep (mbd_sweep_run); a "step" is one diffusion step of all 8 plans and `value`
-                     counts plan-steps/sec
+                     counts plan-steps/sec.  With G > 1 GPUs the plans are REPLICAS over the ranks (seeds r*8/G ...
+                     per rank, no communication inside a run, rewards gathered once at the end): strong = the
+                     reference's 8 plans over G GPUs, weak = 8 plans per GPU
 Ndiffuse=100, seed 0, disable_recommended_params everywhere.
 
 --scaling with G > 1 GPUs (candidates are sharded over ranks, ONE all-gather of the N mean rewards per step):
@@ -33,6 +35,10 @@ Ndiffuse=100, seed 0, disable_recommended_params everywhere.
    weak              N candidates PER GPU, N_total = N*G; `value` is then normalised to N-candidate steps.
 Both are measured in every multi-GPU run; the one not selected is reported under "other_scaling".
 Inputs are resident in HBM when the timed region starts; data is synthetic (seeded PRNG).
+
+The timed region is EXACTLY K steps between two fences (barrier + device synchronisation); it is repeated --repeats
+times (default 5) inside the one command and `value` is the MEDIAN block (`value_min` / `value_max` beside it): one
+block of 20 steps is 11 ms, and box-to-box noise is larger than any round's gain.
 """
 import argparse
 import contextlib
@@ -48,7 +54,7 @@ for p in (ROOT, os.path.join(ROOT, "model-based-diffusion_amd")):
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TF = 157.3   # MI355X_MICROARCH.md: vector FP32 peak
-ROUND = "r03"
+ROUND = "r04"
 
 CONFIGS = {
     # name: env, N, H, Ndiffuse, temp, demo, lanes per candidate (rollout kernel), kernel label
@@ -189,7 +195,7 @@ def cpu_baseline(cfg, seconds_budget=15.0):
     ref_rec, ref_why = reference_baseline(cfg)
     port, fsub = port_baseline(cfg, seconds_budget)
     if ref_rec is not None:
-        ref_rec["port"] = {k: port[k] for k in ("value", "cores", "sample")}
+        ref_rec["port"] = {k: port[k] for k in ("value", "cores", "physical_cores", "phase_ms", "sample")}
         return ref_rec, fsub
     port["reference_attempt"] = ref_why
     return port, fsub
@@ -228,19 +234,36 @@ def port_baseline(cfg, seconds_budget=15.0):
     sched = orc.schedule(1e-4, 1e-2, Nd)
     Ybar = np.zeros((H, env.Nu), np.float32)
     r = orc.split(rng, 2, 1)[0]
+    # one untimed step first: the OpenMP runtime starts its threads, the pages of the buffers get touched
+    op.reverse_once(orc, env, state0, Nd - 1, r, Ybar, sched, N, H, temp, 1, enable_demo=cfg["demo"])
     steps, t0 = 0, time.time()
     i = Nd - 1
+    phases = {}
     while True:
-        r, Ybar, _, _ = op.reverse_once(orc, env, state0, i, r, Ybar, sched, N, H, temp, 1, enable_demo=cfg["demo"])
+        r, Ybar, _, _ = op.reverse_once(orc, env, state0, i, r, Ybar, sched, N, H, temp, 1, enable_demo=cfg["demo"],
+                                        timers=phases)
         steps += 1
         i -= 1
         if time.time() - t0 > seconds_budget or i < 1:  # 10-15 s of host work, at most one whole plan
             break
     dt = time.time() - t0
-    cores = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
-    return {"value": steps / dt, "unit": "diffusion-steps/sec", "cores": cores, "kind": "port",
+    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
+    try:  # physical cores beside the hardware threads OpenMP uses (SMT siblings share the FP units)
+        import psutil
+        physical = psutil.cpu_count(logical=False)
+    except Exception:  # noqa: BLE001
+        physical = None
+    phase_ms = {k: 1e3 * v / steps for k, v in phases.items()}
+    # every phase runs on all threads (oracle/mbd_oracle_core.c: the sampler over candidates, the weighted mean over its
+    # columns; oracle/mbd_oracle_physics.c: the rollout over candidates); what stays serial inside a step is the [N]
+    # standardise / softmax arithmetic (canonical reduction order), mean_H and the Python glue: the share of the step
+    # outside the three timed library phases plus the score phase's serial part is reported as `serial_share_upper_bound`
+    serial = max(0.0, dt - sum(phases.values())) + phases.get("score", 0.0)
+    return {"value": steps / dt, "unit": "diffusion-steps/sec", "cores": threads, "physical_cores": physical,
+            "kind": "port", "phase_ms": phase_ms, "serial_share_upper_bound": serial / dt,
             "sample": f"{steps} consecutive reverse-diffusion steps of {name} N={N} H={H} "
-                      f"(CPU oracle, OpenMP over candidates, {dt:.1f} s)"}, fsub
+                      f"(CPU oracle, OpenMP over candidates in sampler, rollout and weighted mean, {threads} threads, "
+                      f"{dt:.1f} s)"}, fsub
 
 
 def main():
@@ -250,6 +273,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--config", choices=sorted(CONFIGS), default="metric")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed blocks of exactly --steps steps each (fenced on both sides); `value` is the median block")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-final-reward", action="store_true")
     ap.add_argument("--no-extras", action="store_true",
@@ -302,38 +327,71 @@ def main():
     stream = torch.cuda.current_stream(dev).cuda_stream
     rows = 2 if DEMO else 1
 
-    def measure_sweep(P=None, steps=None, warmup=None):
-        """config sweep8: K lockstep diffusion steps of P plans (mbd_sweep_run with Ndiffuse = K + 1).  No per-step host read: the reference's sweep prints nothing per step either (not_render runs of
-        run_diffusion keep their progress bar, but the sweep's measure is the time of whole runs)."""
+    def fence():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    def max_over_ranks(x):
+        if not distributed:
+            return float(x)
+        t = torch.tensor([x], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def sweep_keys_states(seeds):
+        keys, states = [], []
+        for sd in seeds:
+            rng, rng_reset = _capi.prng_split(_capi.prng_key(int(sd)), 2)
+            states.append(env.reset(rng_reset))
+            keys.append(_capi.prng_split(rng, 2)[0])  # rng_exp (:150)
+        return np.array(keys, np.uint32), states
+
+    def measure_sweep(seeds, steps=None, warmup=None, repeats=None):
+        """config sweep8: blocks of K lockstep diffusion steps of the plans with these seeds (mbd_sweep_run with
+        Ndiffuse = K + 1, no host outputs: the timed region is the K steps and nothing else).  No per-step host read: the
+        reference's sweep prints nothing per step either (not_render runs of run_diffusion keep their progress bar, but
+        the sweep's measure is the time of whole runs).  Returns (seconds of every block — max over ranks —, average
+        rollout-launch ms, launches, this rank's own seconds per block)."""
         from mbd_hip.planners.mbd_planner import Sweep
-        P = P or cfg["plans"]
+        P = len(seeds)
         steps, warmup = steps or args.steps, (args.warmup if warmup is None else warmup)
-        # ONE sweep object (its buffers are touched by the warm-up, not by the timed run): a warm-up run of all its steps
-        # (K >= W untimed steps), the timed run of the same K steps, and a third run with HIP events around the rollout
-        # launches for the kernel time (two event records cost a lockstep step ~7 us, 0.7 % — the value run has none)
-        nd = steps + 1  # (the timed run is exactly K steps)
+        repeats = repeats or args.repeats
+        # ONE sweep object (its buffers are touched by the warm-up, not by the timed runs): warm-up runs of all its steps
+        # (K >= W untimed steps), R timed runs of the same K steps, and one more run with HIP events around the rollout
+        # launches for the kernel time (two event records cost a lockstep step ~7 us, 0.7 % — the value runs have none)
+        nd = steps + 1  # (a timed run is exactly K steps)
         a = Args(seed=0, env_name=ENV, Nsample=N_CFG, Hsample=H, Ndiffuse=max(nd, 2), temp_sample=TEMP,
                  disable_recommended_params=True, not_render=True)
         sw = Sweep(env, a, P)
-        keys = []
-        for k in range(P):
-            rng, rng_reset = _capi.prng_split(_capi.prng_key(k), 2)
-            sw.set_state0(k, env.reset(rng_reset))
-            keys.append(_capi.prng_split(rng, 2)[0])
-        keys = np.array(keys, np.uint32)
-        done = 0
-        while done < max(warmup, 1):  # warm-up: whole runs until at least W steps have been taken
-            sw.run(keys)
-            done += steps
-        torch.cuda.synchronize(dev)
-        _, _, _, secs_value = sw.run(keys)
-        torch.cuda.synchronize(dev)
-        sw.kernel_time(enable=True)
-        sw.run(keys)
-        torch.cuda.synchronize(dev)
-        kern_ms, kern_n = sw.kernel_time(enable=False)
-        sw.close()
-        return secs_value, kern_ms, kern_n
+        try:
+            keys, states = sweep_keys_states(seeds)
+            for k, st0 in enumerate(states):
+                sw.set_state0(k, st0)
+            done = 0
+            while done < max(warmup, 1):  # warm-up: whole runs until at least W steps have been taken
+                sw.run(keys, outputs=False)
+                done += steps
+            blocks, own = [], []
+            for _ in range(repeats):
+                fence()
+                t0 = time.perf_counter()
+                sw.run(keys, outputs=False)
+                torch.cuda.synchronize(dev)
+                own.append(time.perf_counter() - t0)
+                fence()
+                blocks.append(max_over_ranks(time.perf_counter() - t0))
+            sw.kernel_time(enable=True)
+            sw.run(keys, outputs=False)
+            torch.cuda.synchronize(dev)
+            kern_ms, kern_n = sw.kernel_time(enable=False)
+        finally:
+            sw.close()
+        return blocks, kern_ms, kern_n, own
+
+    def sweep_plan_args(seeds):
+        return [Args(seed=int(sd), env_name=ENV, Nsample=N_CFG, Hsample=H, Ndiffuse=ND, temp_sample=TEMP,
+                     disable_recommended_params=True, not_render=True) for sd in seeds]
 
     def measure(N_total, N_local, collective="torch"):
         """K synced + K async steps of a plan with N_total candidates of which this rank owns N_local."""
@@ -413,11 +471,6 @@ def main():
 
         prepare()
 
-        def fence():
-            if distributed:
-                dist.barrier()
-            torch.cuda.synchronize(dev)
-
         def timed(read_back):
             for _ in range(args.warmup):
                 step(read_back)
@@ -429,18 +482,17 @@ def main():
             # moves them (experiments).
             ev_mode = os.environ.get("MBD_BENCH_EVENTS", "async")
             plan.enable_timing(ev_mode == "all" or (ev_mode == "async" and not read_back))
-            t0 = time.perf_counter()
-            for _ in range(args.steps):
-                step(read_back)
-            fence()
-            elapsed = time.perf_counter() - t0
+            blocks = []
+            for _ in range(args.repeats):  # R blocks of exactly K steps, each fenced on both sides
+                fence()
+                t0 = time.perf_counter()
+                for _ in range(args.steps):
+                    step(read_back)
+                fence()
+                blocks.append(max_over_ranks(time.perf_counter() - t0))
             plan.enable_timing(False)
             kern_ms, kern_n = plan.kernel_time()
-            if distributed:
-                t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-                dist.all_reduce(t, op=dist.ReduceOp.MAX)
-                elapsed = float(t.item())
-            return elapsed, kern_ms, kern_n
+            return blocks, kern_ms, kern_n
 
         sync = timed(True)
         asyn = timed(False)
@@ -450,18 +502,38 @@ def main():
         plan.close()
         return sync, asyn
 
+    def med(xs):
+        return float(np.median(np.asarray(xs, np.float64)))
+
     strong_local = max(1, N_CFG // world)
     runs = {"strong": (strong_local * world, strong_local)}
     if world > 1:
         runs["weak"] = (N_CFG * world, N_CFG)
     is_sweep = "plans" in cfg
+    sweep_plans = {}
     if is_sweep:
-        assert world == 1, "config sweep8 is a single-GPU workload (the plans of a sweep are independent: run one per GPU)"
-        sw = measure_sweep()
-        res = {"strong": (sw, sw)}
+        # the reference's only timing protocol (scripts/run_mbd.py:17-39): independent plans -> REPLICAS over the ranks,
+        # no communication inside a run.  strong: the sweep's P plans over the G GPUs (seeds r*P/G ...: at G = P one plan
+        # per GPU, the one-candidate kernel); weak: P plans per GPU, seeds 0..G*P-1
+        P = cfg["plans"]
+        if P % world:
+            raise SystemExit(f"sweep8: {P} plans do not divide over {world} ranks")
+        sweep_plans["strong"] = list(range(rank * (P // world), (rank + 1) * (P // world)))
+        if world > 1:
+            sweep_plans["weak"] = list(range(rank * P, (rank + 1) * P))
+        res = {}
+        for k, seeds in sweep_plans.items():
+            blocks, kms, kn, own = measure_sweep(seeds)
+            res[k] = (blocks, blocks, kms, kn, own)
     else:
         main_coll = "p2p" if args.collective == "p2p" else "torch"
-        res = {k: measure(*v, collective=main_coll) for k, v in runs.items() if k == args.scaling or world > 1}
+        res = {}
+        for k, v in runs.items():
+            if k == args.scaling or world > 1:
+                (bs, _, _), (ba, kms, kn) = sy, asy = measure(*v, collective=main_coll)
+                if kn == 0:  # MBD_BENCH_EVENTS=all / none
+                    kms, kn = sy[1], sy[2]
+                res[k] = (bs, ba, kms, kn, None)
     if args.scaling not in res:  # one GPU, --scaling weak: the same measurement
         res[args.scaling] = res["strong"]
     # the other collective, after the headline measurement and guarded: a failure here (a peer that cannot map a
@@ -472,29 +544,35 @@ def main():
         # values (mbd_hip.planners.exchange_canary).  Peer stores into mapped memory are what ends in an uncatchable GPU
         # fault when a node's peer access is not what the code assumes — that must cost a canary, not this process and
         # its RCCL measurement.  Every rank learns the worst exit status before anybody goes on.
+        import shutil
         import subprocess
         import tempfile
-        rdv = os.path.join(tempfile.gettempdir(), f"mbd_canary_{os.environ.get('MASTER_PORT', '0')}_{world}")
+        # a FRESH rendezvous directory per run (rank 0 makes it, everybody learns its name): files of a crashed earlier
+        # run — stale IPC handles, stale barrier files — can never be read
+        box = [tempfile.mkdtemp(prefix="mbd_canary_") if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        rdv = box[0]
         try:
-            cp = subprocess.run([sys.executable, "-m", "mbd_hip.planners.exchange_canary", str(rank), str(world),
-                                 str(local_rank), rdv], cwd=os.path.join(ROOT, "model-based-diffusion_amd"),
-                                capture_output=True, text=True, timeout=240)
-            canary_rc, canary_err = cp.returncode, cp.stderr[-300:]
-        except Exception as e:  # noqa: BLE001
-            canary_rc, canary_err = 99, f"{type(e).__name__}: {e}"
-        worst = torch.tensor([abs(canary_rc)], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
-        if rank == 0:
-            import shutil
-            shutil.rmtree(rdv, ignore_errors=True)
+            try:
+                cp = subprocess.run([sys.executable, "-m", "mbd_hip.planners.exchange_canary", str(rank), str(world),
+                                     str(local_rank), rdv], cwd=os.path.join(ROOT, "model-based-diffusion_amd"),
+                                    capture_output=True, text=True, timeout=240)
+                canary_rc, canary_err = cp.returncode, cp.stderr[-300:]
+            except Exception as e:  # noqa: BLE001
+                canary_rc, canary_err = 99, f"{type(e).__name__}: {e}"
+            worst = torch.tensor([abs(canary_rc)], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        finally:
+            if rank == 0:
+                shutil.rmtree(rdv, ignore_errors=True)
         if int(worst.item()) != 0:
             other_coll = {"collective": "p2p", "error": f"canary failed (worst exit status {int(worst.item())}; rank {rank}: "
                                                             f"{canary_rc} {canary_err.strip()[-200:]})"}
     if distributed and world > 1 and args.collective == "both" and not is_sweep and other_coll is None:
         try:
-            oc = measure(*runs[args.scaling], collective="p2p")
+            (ocs, _, _), (oca, okms, _) = measure(*runs[args.scaling], collective="p2p")
             other_coll = {"collective": "p2p (mbd_exchange_*: hipIpc-mapped windows, peer stores + epoch flags)",
-                          "elapsed": oc[0][0], "elapsed_async": oc[1][0], "kernel_avg_ms": oc[1][1]}
+                          "elapsed": med(ocs), "elapsed_async": med(oca), "kernel_avg_ms": okms}
         except Exception as e:  # noqa: BLE001
             other_coll = {"collective": "p2p", "error": f"{type(e).__name__}: {e}"}
         ok = torch.tensor([0 if "error" in other_coll else 1], dtype=torch.int32, device=dev if backend == "nccl" else "cpu")
@@ -514,7 +592,22 @@ def main():
         phase_ms = det["phase_ms"]
 
     final = None
-    if not args.no_final_reward and (rank == 0 or distributed):
+    if not args.no_final_reward and is_sweep:
+        # the sweep's second half: rew_final of the COMPLETE plans (Ndiffuse of the config), every rank its own seeds in one
+        # sweep, gathered once at the end; rank 0 then runs all of them as ONE sweep on its GPU — plans are independent,
+        # the two must agree bit for bit
+        # (the product's multi-GPU sweep: mbd_hip.scripts.run_mbd.run_replicated)
+        from mbd_hip.scripts.run_mbd import run_concurrent, run_replicated
+        P = cfg["plans"]
+        rews, _, _ = run_replicated(sweep_plan_args(range(P)), device=local_rank)
+        final = {"seeds": list(range(P)), "rew_final": rews, "mean": float(np.mean(rews)), "std": float(np.std(rews)),
+                 "N": N_CFG}
+        if distributed and rank == 0:
+            single, _, _ = run_concurrent(sweep_plan_args(range(P)), local_rank)
+            final["replicated_over"] = world
+            final["equals_one_gpu_bitwise"] = bool(np.array_equal(np.float32(rews), np.float32(single)))
+            final["rew_final_one_gpu"] = single
+    elif not args.no_final_reward and (rank == 0 or distributed):
         # the metric's second half: final reward of complete plans, seeds 0..7 as mbd/scripts/run_mbd.py:20.  With
         # G > 1 ranks every plan runs SHARDED over the ranks (the product's multi-GPU path: run_diffusion ->
         # reverse_distributed) and, on rank 0, once more on one GPU: the two must agree bit for bit (variant B: every
@@ -535,49 +628,71 @@ def main():
             final["equals_one_gpu_bitwise"] = bool(np.array_equal(np.float32(rews), np.float32(single)))
             final["rew_final_one_gpu"] = single
 
-    # Short extra measurements that ride in the default line (one GPU, config `metric`): what round 3 built for the sizes
-    # above the metric's — the reference's own default humanoidrun plan (N = 8192, mbd_planner.py:54-60) and its 8-seed
-    # sweep (scripts/run_mbd.py:17-39) — so that the driver's record of this command holds them too.  ~3 s.
+    # Short extra measurements that ride in the default line (one GPU, config `metric`): the sizes above the metric's —
+    # the reference's own default humanoidrun plan (N = 8192, mbd_planner.py:54-60) and its 8-seed sweep
+    # (scripts/run_mbd.py:17-39) — so that the driver's record of this command holds them too.  ~3 s.  Each extra is
+    # guarded on its own: a failure is reported as {"error": ...} under its name and never costs the line its value.
     extras = None
     if rank == 0 and not distributed and args.config == "metric" and not args.no_extras and not os.environ.get("MBD_BENCH_N"):
         extras = {}
-        try:
+
+        def extra_big():
             a = Args(seed=0, env_name=ENV, Nsample=8192, Hsample=H, Ndiffuse=41, temp_sample=TEMP,
                      disable_recommended_params=True, not_render=True)
             rng0, rng_reset = _capi.prng_split(_capi.prng_key(0), 2)
             big = Plan(env, a)
-            big.set_state0(env.reset(rng_reset))
-            big.run(_capi.prng_split(rng0, 2)[0])            # warm-up
-            big.enable_timing(True)
-            _, _, _, secs = big.run(_capi.prng_split(rng0, 2)[0])
-            big.enable_timing(False)
-            kms, _ = big.kernel_time()
-            big.close()
-            extras["humanoidrun8192"] = {"workload": "humanoidrun N=8192 H=50, 40 steps of mbd_plan_run (no per-step host read)",
-                                         "steps_per_sec": 40 / secs, "kernel_avg_ms": kms, "_candidates": 8192,
-                                         "kernel": CONFIGS["humanoidrun8192"]["kernel"]}
-            cfg_sw = dict(CONFIGS["sweep8"])
-            sw_secs, sw_kms, _ = measure_sweep(P=cfg_sw["plans"], steps=40, warmup=5)
-            extras["sweep8"] = {"workload": "8 plans x humanoidrun N=1024 H=50 in lockstep, 40 steps of mbd_sweep_run",
-                                "plan_steps_per_sec": cfg_sw["plans"] * 40 / sw_secs, "kernel_avg_ms": sw_kms,
-                                "_candidates": 8192, "kernel": cfg_sw["kernel"]}
-        except Exception as e:  # noqa: BLE001 — extras never cost the line its value
-            extras["error"] = f"{type(e).__name__}: {e}"
+            try:
+                big.set_state0(env.reset(rng_reset))
+                big.run(_capi.prng_split(rng0, 2)[0])            # warm-up
+                secs = [big.run(_capi.prng_split(rng0, 2)[0])[3] for _ in range(3)]
+                big.enable_timing(True)
+                big.run(_capi.prng_split(rng0, 2)[0])
+                big.enable_timing(False)
+                kms, _ = big.kernel_time()
+            finally:
+                big.close()
+            return {"workload": "humanoidrun N=8192 H=50, 40 steps of mbd_plan_run (no per-step host read), median of 3 runs",
+                    "steps_per_sec": 40 / med(secs), "kernel_avg_ms": kms, "_candidates": 8192,
+                    "kernel": CONFIGS["humanoidrun8192"]["kernel"]}
+
+        def extra_sweep():
+            cfg_sw = CONFIGS["sweep8"]
+            blocks, sw_kms, _, _ = measure_sweep(list(range(cfg_sw["plans"])), steps=40, warmup=5, repeats=3)
+            return {"workload": "8 plans x humanoidrun N=1024 H=50 in lockstep, 40 steps of mbd_sweep_run, median of 3 runs",
+                    "plan_steps_per_sec": cfg_sw["plans"] * 40 / med(blocks), "kernel_avg_ms": sw_kms,
+                    "_candidates": 8192, "kernel": cfg_sw["kernel"]}
+
+        for name, fn in (("humanoidrun8192", extra_big), ("sweep8", extra_sweep)):
+            try:
+                extras[name] = fn()
+            except Exception as e:  # noqa: BLE001 — extras never cost the line its value
+                extras[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    per_rank = None
+    if is_sweep and distributed:  # every rank's own rate (its plans, its clock), for the line
+        own = res[args.scaling][4]
+        mine = len(sweep_plans[args.scaling]) * args.steps / med(own)
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        per_rank = box
 
     if rank == 0:
         def rate(mode, which):
-            (el_s, _, _), (el_a, _, _) = res[mode]
-            el = el_s if which == "sync" else el_a
-            N_total, _ = runs.get(mode, runs["strong"])
-            return (args.steps / el) * (N_total / N_CFG if mode == "weak" else 1.0), 1e3 * el / args.steps
+            """(median, min, max) rate and the median ms per step of the leg's R blocks"""
+            bs, ba = res[mode][0], res[mode][1]
+            blocks = bs if which == "sync" else ba
+            if is_sweep:
+                units = len(sweep_plans.get(mode, sweep_plans["strong"])) * world * args.steps  # plan-steps per block
+            else:
+                N_total, _ = runs.get(mode, runs["strong"])
+                units = args.steps * (N_total / N_CFG if mode == "weak" else 1.0)
+            return units / med(blocks), units / max(blocks), units / min(blocks), 1e3 * med(blocks) / args.steps
 
         mode = args.scaling
-        (el_s, kern_ms_s, kern_n_s), (el_a, kern_ms, kern_n) = res[mode]
-        if kern_n == 0:  # MBD_BENCH_EVENTS=all / none
-            kern_ms, kern_n = kern_ms_s, kern_n_s
+        kern_ms, kern_n = res[mode][2], res[mode][3]
         N_total, N_local = runs.get(mode, runs["strong"])
-        value, ms_sync = rate(mode, "sync")
-        value_async, ms_async = rate(mode, "async")
+        value, vmin, vmax, ms_sync = rate(mode, "sync")
+        value_async, amin, amax, ms_async = rate(mode, "async")
         balg = b_alg_bytes(N_local, H, Nu, DEMO)
         achieved = (balg / 1e9) / (kern_ms / 1e3) if kern_ms > 0 else 0.0
         traffic, traffic_src = pmc_traffic(args.config)
@@ -587,7 +702,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms_sync, "higher_is_better": True, "scaling": mode,
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "value_async": value_async, "ms_per_step_async": ms_async,
+            "repeats": args.repeats, "value_min": vmin, "value_max": vmax,
+            "value_note": f"median of {args.repeats} timed blocks of exactly {args.steps} steps, each fenced (barrier + "
+                          "device synchronisation) on both sides, max over ranks per block",
+            "value_async": value_async, "value_async_min": amin, "value_async_max": amax, "ms_per_step_async": ms_async,
             "config": {"workload": f"{args.config}: {ENV} N_total={N_total} ({N_local}/GPU) H={H} Ndiffuse={ND} "
                                    f"temp={TEMP}{' enable_demo' if DEMO else ''} seed=0 disable_recommended_params",
                        "name": args.config, "N_total": N_total, "N_per_gpu": N_local, "H": H, "Nu": Nu,
@@ -601,27 +719,36 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": cfg["kernel"], "kernel_avg_ms": kern_ms,
                          "kernel_launches": kern_n, "kernel_timing": "HIP events around every rollout launch of the "
-                         "value_async leg (same K steps; the value leg runs without them: two event records cost a "
+                         "value_async leg (same R x K steps; the value leg runs without them: two event records cost a "
                          "step ~7.5 us)", "algorithmic_bytes_per_launch": balg,
                          "note": "state stays in VGPRs for all H*n_frames substeps: the kernel is bound by "
                                  "dependent FP32 VALU issue, not HBM (DESIGN.md §Roofline)"},
             "final_reward": final,
         }
-        if is_sweep:  # plan-steps: K lockstep steps of P plans
+        n_valu = N_local
+        if is_sweep:  # plan-steps: K lockstep steps of the plans
             P = cfg["plans"]
-            out["value"] = out["value_async"] = P * args.steps / el_a
-            out["ms_per_step"] = out["ms_per_step_async"] = 1e3 * el_a / args.steps
-            out["unit"] = f"plan-steps/sec: diffusion steps of the {P} plans of a seed sweep advanced in lockstep (mbd_sweep_run)"
-            out["config"]["workload"] = (f"sweep8: {P} plans x {ENV} N={N_CFG} H={H} temp={TEMP}, seeds 0..{P - 1}, one rollout "
-                                         f"launch over {P * N_CFG} candidates + one score launch per step")
-            out["config"]["plans"] = P
-            bal = P * b_alg_bytes(N_CFG, H, Nu, DEMO)
+            p_local = len(sweep_plans[mode])
+            out["unit"] = (f"plan-steps/sec: diffusion steps of the plans of a seed sweep ({p_local} per GPU in lockstep, "
+                           "mbd_sweep_run; replicas over the GPUs, no communication inside a run)")
+            out["config"]["workload"] = (f"sweep8: {p_local * world} plans x {ENV} N={N_CFG} H={H} temp={TEMP}, seeds "
+                                         f"0..{p_local * world - 1}, {p_local} per GPU: one rollout launch over "
+                                         f"{p_local * N_CFG} candidates + one score launch per step and GPU")
+            out["config"].update(plans=p_local * world, plans_per_gpu=p_local, N_total=p_local * world * N_CFG,
+                                 N_per_gpu=p_local * N_CFG,
+                                 collective="none inside a run (independent plans); rew_final gathered once at the end")
+            if p_local * N_CFG <= 4096:  # (the launch selection of csrc: two candidates per lane above 4096 candidates)
+                out["roofline"]["kernel"] = CONFIGS["metric"]["kernel"] + f" over {p_local} plan(s) x {N_CFG} candidates"
+            bal = p_local * b_alg_bytes(N_CFG, H, Nu, DEMO)
             out["roofline"].update(achieved=(bal / 1e9) / (kern_ms / 1e3) if kern_ms > 0 else 0.0,
                                    algorithmic_bytes_per_launch=bal)
             out["roofline"]["frac"] = out["roofline"]["achieved"] / HBM_PEAK_GBS
             out["roofline"]["traffic"] = None
-            out["roofline"]["kernel_timing"] = ("HIP events around every rollout launch of a SECOND run of the same K "
-                                                "lockstep steps (the value run carries no events)")
+            out["roofline"]["kernel_timing"] = ("HIP events around every rollout launch of one MORE run of the same K "
+                                                "lockstep steps (the value runs carry no events)")
+            if per_rank is not None:
+                out["per_rank_plan_steps_per_sec"] = per_rank
+            n_valu = p_local * N_CFG
         if phase_ms is not None:
             out["phase_ms"] = phase_ms
         if other_coll is not None:
@@ -633,22 +760,29 @@ def main():
             out["other_collective"] = other_coll
         if world > 1:
             other = "weak" if mode == "strong" else "strong"
-            ov, oms = rate(other, "sync")
-            oa, _ = rate(other, "async")
-            out["other_scaling"] = {"scaling": other, "value": ov, "ms_per_step": oms, "value_async": oa,
-                                    "N_total": runs[other][0], "N_per_gpu": runs[other][1]}
+            ov, _, _, oms = rate(other, "sync")
+            oa, _, _, _ = rate(other, "async")
+            out["other_scaling"] = {"scaling": other, "value": ov, "ms_per_step": oms, "value_async": oa}
+            if is_sweep:
+                out["other_scaling"].update(plans=len(sweep_plans[other]) * world, plans_per_gpu=len(sweep_plans[other]))
+            else:
+                out["other_scaling"].update(N_total=runs[other][0], N_per_gpu=runs[other][1])
         fsub, fsub_src = op_counts(ENV)
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"], live = cpu_baseline(cfg)
             if live:
                 fsub, fsub_src = live, "oracle/count_ops.cc (this run)"
-        out["valu"] = valu_view(cfg, N_local * cfg.get("plans", 1), kern_ms, n_frames, fsub, fsub_src)
+        if is_sweep and n_valu <= 4096:  # (the one-candidate kernel's geometry and static counts)
+            cfg = dict(cfg, cpw=4, static="humanoidrun")
+        out["valu"] = valu_view(cfg, n_valu, kern_ms, n_frames, fsub, fsub_src)
         if extras is not None:
-            for k, e in extras.items():  # (the VALU view of the extra workloads needs the op count of this line)
-                if fsub and e.get("kernel_avg_ms"):
-                    e["valu_algorithmic_frac"] = (float(fsub["flops"]) * e.pop("_candidates") * H * n_frames /
+            for e in extras.values():  # (the VALU view of the extra workloads needs the op count of this line)
+                if not isinstance(e, dict):
+                    continue
+                cands = e.pop("_candidates", None)
+                if fsub and cands and e.get("kernel_avg_ms"):
+                    e["valu_algorithmic_frac"] = (float(fsub["flops"]) * cands * H * n_frames /
                                                   (e["kernel_avg_ms"] * 1e-3) / 1e12 / VALU_PEAK_TF)
-                e.pop("_candidates", None)
             out["extras"] = extras
         print(json.dumps(out))
     if distributed:

@@ -303,6 +303,11 @@ int mbd_plan_get_sigma(mbd_plan* plan, float* sigma_out);
  * place; d_rew_mean [1]. */
 int mbd_plan_reverse_once(mbd_plan* plan, int i, uint32_t key_inout[2], float* d_Ybar,
                           float* d_rew_mean, void* stream);
+/* Host blocking of the phase calls: a plan whose next step's normals are generated on its second stream (plans that
+ * fill the chip) keeps the host at most one step ahead of the device — mbd_plan_sample_rollout may then sleep up to 5 ms
+ * (mbd_plan_run / mbd_sweep_run: 20 ms) for the previous rollout to START; when the stream is slower than that (a shared
+ * or time-sliced GPU, earlier work on the caller's stream, a profiler) the call falls back to ordering its two streams
+ * with an event and returns — a slow stream is never an error. */
 /* whole reverse loop = reverse() (mbd_planner.py:138-148) + final evaluation (:179-180).
  * key = rng_exp of (:150).  mu_0ts_out HOST [Ndiffuse-1][H][Nu] (the array saved at :156),
  * rew_means_out HOST [Ndiffuse-1] (the tqdm postfix values, :147) — either may be NULL.
@@ -358,8 +363,13 @@ int mbd_sweep_kernel_time(mbd_sweep* sweep, int enable, float* avg_ms_out, int* 
 typedef struct mbd_exchange mbd_exchange;
 #define MBD_IPC_HANDLE_BYTES 64
 #define MBD_EXCHANGE_MAX_RANKS 16
-/* rank `rank` of `world` (<= MBD_EXCHANGE_MAX_RANKS) on `device`: rows x shard floats per rank and step */
+/* rank `rank` of `world` (<= MBD_EXCHANGE_MAX_RANKS) on `device`: rows x shard floats per rank and step.  The window is
+ * FINE-GRAINED device memory (peers' stores and the owner's loads meet at system scope); a runtime without such a pool
+ * gets MBD_ERR_UNSUPPORTED — keep the collective library's all-gather then (a coarse-grained window can hand the owner
+ * a flag beside stale rewards). */
 int mbd_exchange_create(int device, int rank, int world, int rows, int shard, mbd_exchange** out);
+/* 1: the window is fine-grained memory (always, unless the test lever MBD_EXCHANGE_COARSE_OK allowed otherwise) */
+int mbd_exchange_fine_grained(const mbd_exchange* x, int* out);
 int mbd_exchange_destroy(mbd_exchange* x);
 /* this rank's window as an IPC handle (MBD_IPC_HANDLE_BYTES bytes, HOST).  The caller passes the handles around by
  * any host channel (torch.distributed.all_gather_object, MPI, a file) and hands all of them to _connect. */

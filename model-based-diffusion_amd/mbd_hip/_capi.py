@@ -44,7 +44,7 @@ EXPORTS = [
     "mbd_plan_enable_timing",
     "mbd_sweep_create", "mbd_sweep_destroy", "mbd_sweep_set_state0", "mbd_sweep_run", "mbd_sweep_kernel_time",
     "mbd_exchange_create", "mbd_exchange_destroy", "mbd_exchange_local_handle", "mbd_exchange_connect",
-    "mbd_exchange_all_gather", "mbd_exchange_status",
+    "mbd_exchange_all_gather", "mbd_exchange_status", "mbd_exchange_fine_grained",
 ]
 
 _lib = None
@@ -117,6 +117,7 @@ def load() -> C.CDLL:
     lib.mbd_exchange_connect.argtypes = [_vp, _vp]
     lib.mbd_exchange_all_gather.argtypes = [_vp, _vp, C.POINTER(_vp), _vp]
     lib.mbd_exchange_status.argtypes = [_vp]
+    lib.mbd_exchange_fine_grained.argtypes = [_vp, C.POINTER(_i)]
     _lib = lib
     return lib
 

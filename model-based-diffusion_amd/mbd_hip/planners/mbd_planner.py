@@ -84,14 +84,18 @@ class Sweep:
         st = np.ascontiguousarray(state.pipeline_state, np.float32).reshape(-1)
         _capi.check(self.lib.mbd_sweep_set_state0(self.h, int(k), _capi.np_ptr(st)))
 
-    def run(self, keys):
+    def run(self, keys, outputs: bool = True):
         """keys [P, 2] = rng_exp of every plan.  Returns (mu_0ts [P, Nd-1, H, Nu], rew_means [P, Nd-1], rew_final [P],
-        seconds of the lockstep loop)."""
+        seconds of the lockstep loop).  ``outputs=False``: the lockstep loop only — no host copies, no final evaluation
+        (timing runs); the three arrays are then None."""
         k = np.ascontiguousarray(keys, np.uint32).reshape(self.P, 2)
+        secs = C.c_double()
+        if not outputs:
+            _capi.check(self.lib.mbd_sweep_run(self.h, _capi.np_ptr(k), None, None, None, C.byref(secs)))
+            return None, None, None, secs.value
         mu = np.zeros((self.P, self.Nd - 1, self.H, self.Nu), np.float32)
         rm = np.zeros((self.P, self.Nd - 1), np.float32)
         rf = np.zeros(self.P, np.float32)
-        secs = C.c_double()
         _capi.check(self.lib.mbd_sweep_run(self.h, _capi.np_ptr(k), _capi.np_ptr(mu), _capi.np_ptr(rm), _capi.np_ptr(rf),
                                            C.byref(secs)))
         return mu, rm, rf, secs.value

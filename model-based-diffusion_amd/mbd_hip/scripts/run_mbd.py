@@ -128,6 +128,37 @@ def run_concurrent(plan_args, device: int = 0, batched: bool | None = None):
     return rews, mus, secs
 
 
+def replica_bounds(P: int, world: int, rank: int):
+    """Plans [begin, begin + count) of a sweep of P independent plans owned by `rank`: contiguous, as equal as possible
+    (the first P % world ranks take one more)."""
+    if P < 0 or world < 1 or not 0 <= rank < world:
+        raise ValueError(f"replica_bounds({P}, {world}, {rank})")
+    base, extra = divmod(P, world)
+    return rank * base + min(rank, extra), base + (1 if rank < extra else 0)
+
+
+def run_replicated(plan_args, device: int | None = None, group=None):
+    """The multi-GPU form of a sweep (run_mbd.py:17-64): its plans are independent, so with ``torch.distributed``
+    initialised they are REPLICAS over the ranks — rank r runs plans replica_bounds(P, world, r) on its GPU through
+    run_concurrent (one mbd_sweep per rank), nothing is exchanged while they run, and the results are gathered ONCE at the
+    end (all_gather_object of the final rewards and mu_0ts).  Every rank returns the same (rew_final list in plan order,
+    mu_0ts list, max over ranks of the batch seconds); bit-identical to run_concurrent(plan_args) on one GPU."""
+    import os
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if world == 1:
+        return run_concurrent(plan_args, 0 if device is None else device)
+    rank = dist.get_rank(group)
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    begin, count = replica_bounds(len(plan_args), world, rank)
+    own = list(plan_args[begin:begin + count])
+    rews, mus, secs = run_concurrent(own, device) if own else ([], [], 0.0)
+    box = [None] * world
+    dist.all_gather_object(box, ([float(r) for r in rews], [np.asarray(m) for m in mus], float(secs)), group=group)
+    return ([r for part in box for r in part[0]], [m for part in box for m in part[1]], max(part[2] for part in box))
+
+
 def _run_path_integral_seq(arg_list, device):
     """The path-integral baselines (run_mbd.py:22-26,46-50) run one plan after another, each timed end to end like
     the reference does (`time()` around the call, :21,34)."""
@@ -140,38 +171,38 @@ def _run_path_integral_seq(arg_list, device):
     return np.array(rews), np.array(times)
 
 
-def run_multiple_seed(args: Args, device: int = 0, **plan_kw):
+def run_multiple_seed(args: Args, device: int | None = None, **plan_kw):
     """run_mbd.py:17-39: seeds 0..7, mean +- std of the final reward and the time."""
     if args.algo == "path_integral":  # :22-26
         from ..planners import path_integral
         rews, times = _run_path_integral_seq(
             [path_integral.Args(seed=seed, env_name=args.env_name, update_method=args.update_method, **plan_kw)
-             for seed in range(8)], device)
+             for seed in range(8)], device or 0)
         print(f"rew: {rews.mean():.2f} \\pm {rews.std():.2f}")
         print(f"time: {times.mean():.2f} \\pm {times.std():.2f}")
         return rews, float(times.sum())
     if args.algo != "mbd":
         raise NotImplementedError  # :32-33
     plans = [mbd_planner.Args(seed=seed, env_name=args.env_name, not_render=True, **plan_kw) for seed in range(8)]
-    rews, _, secs = run_concurrent(plans, device)
+    rews, _, secs = run_replicated(plans, device)  # (one GPU: run_concurrent; several: the plans as replicas over ranks)
     rews = np.array(rews)
     print(f"rew: {rews.mean():.2f} \\pm {rews.std():.2f}")
     print(f"time: {secs / len(plans):.2f} per plan ({secs:.2f} s for the concurrent batch of {len(plans)})")
     return rews, secs
 
 
-def run_multiple_temp(args: Args, device: int = 0, **plan_kw):
+def run_multiple_temp(args: Args, device: int | None = None, **plan_kw):
     """run_mbd.py:42-64: temperature sweep at seed 0 (mbd: recommended params disabled; path_integral: the
     reference neither disables them nor forwards update_method, :46-50 — replicated, not "fixed")."""
     temps = np.array([0.01, 0.03, 0.06, 0.1, 0.2, 0.4, 0.6, 0.8])
     if args.algo == "path_integral":
         from ..planners import path_integral
         rews, _ = _run_path_integral_seq(
-            [path_integral.Args(seed=0, env_name=args.env_name, temp_sample=float(t), **plan_kw) for t in temps], device)
+            [path_integral.Args(seed=0, env_name=args.env_name, temp_sample=float(t), **plan_kw) for t in temps], device or 0)
     elif args.algo == "mbd":
         plans = [mbd_planner.Args(seed=0, env_name=args.env_name, temp_sample=float(t), not_render=True,
                                   disable_recommended_params=True, **plan_kw) for t in temps]
-        rews, _, _ = run_concurrent(plans, device)
+        rews, _, _ = run_replicated(plans, device)
         rews = np.array(rews)
     else:
         raise NotImplementedError

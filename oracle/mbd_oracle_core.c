@@ -185,17 +185,27 @@ ORC_API void orc_sample(const uint32_t key_sample[2], int impl, int N, int HNu, 
                         float sigma, const float* Ybar, float* Y0s /* [count][HNu] */,
                         float* eps_opt /* [count][HNu] or NULL */) {
   const uint64_t size = (uint64_t)N * (uint64_t)HNu;
-  float* row = (float*)malloc(sizeof(float) * (size_t)HNu);
-  for (int n = 0; n < count; ++n) {
-    orc_normal(key_sample, impl, (uint64_t)(begin + n) * (uint64_t)HNu, (uint64_t)HNu, size, row);
-    for (int e = 0; e < HNu; ++e) {
-      float y = row[e] * sigma + Ybar[e];
-      y = y < -1.0f ? -1.0f : (y > 1.0f ? 1.0f : y);
-      Y0s[(size_t)n * HNu + e] = y;
-      if (eps_opt) eps_opt[(size_t)n * HNu + e] = row[e];
+  /* counter-based noise: every element depends on (key, flat index) only, so the rows are independent — the OpenMP
+   * build (the all-core cpu_baseline of bench.py) spreads them over the cores; same values in any order */
+#ifdef _OPENMP
+#pragma omp parallel
+#endif
+  {
+    float* row = (float*)malloc(sizeof(float) * (size_t)HNu);
+#ifdef _OPENMP
+#pragma omp for schedule(static)
+#endif
+    for (int n = 0; n < count; ++n) {
+      orc_normal(key_sample, impl, (uint64_t)(begin + n) * (uint64_t)HNu, (uint64_t)HNu, size, row);
+      for (int e = 0; e < HNu; ++e) {
+        float y = row[e] * sigma + Ybar[e];
+        y = y < -1.0f ? -1.0f : (y > 1.0f ? 1.0f : y);
+        Y0s[(size_t)n * HNu + e] = y;
+        if (eps_opt) eps_opt[(size_t)n * HNu + e] = row[e];
+      }
     }
+    free(row);
   }
-  free(row);
 }
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -278,6 +288,10 @@ ORC_API float orc_score_update(int N, int HNu, const float* rews, const float* l
   for (int n = 0; n < N; ++n) weights[n] = weights[n] / den;
   /* Ybar = einsum("n,nij->ij") (:128): wsum64 order */
   const float sab = __builtin_sqrtf(alpha_bar_i);
+  /* (columns are independent; each keeps its canonical wsum64 order — the OpenMP build spreads them over the cores) */
+#ifdef _OPENMP
+#pragma omp parallel for schedule(static)
+#endif
   for (int e = 0; e < HNu; ++e) {
     float Ybar = wsum64(weights, Y0s + e, N, HNu);
     if (literal) { /* :100,130-133 */

@@ -52,22 +52,31 @@ def mean_h(orc: Oracle, rewss):
 
 
 def reverse_once(orc: Oracle, env: OracleEnv, state0, i, rng, Ybar_i, sched, N, H, temp, impl,
-                 enable_demo=False, literal=True):
-    """One step of mbd_planner.py:97-135. Returns (rng', Ybar_im1, rew_mean, details)."""
+                 enable_demo=False, literal=True, timers=None):
+    """One step of mbd_planner.py:97-135. Returns (rng', Ybar_im1, rew_mean, details).  ``timers``: a dict that
+    accumulates the seconds of the three phases (sample / rollout / score) — bench.py's cpu_baseline reports them."""
+    import time
     alphas, alphas_bar, sigmas = sched
+    t0 = time.perf_counter()
     keys = orc.split(rng, 2, impl)  # rng, Y0s_rng = split(rng)  (:103)
     rng, ks = keys[0], keys[1]
     Y0s = orc.sample(ks, impl, N, H, env.Nu, 0, N, float(sigmas[i]), Ybar_i)  # :104-106
+    t1 = time.perf_counter()
     lp = None
     if enable_demo:
         rewss, xpos = env.rollout(state0, Y0s, want_xpos=True)  # :109
         lp = env.logpd(xpos)  # :118
     else:
         rewss = env.rollout(state0, Y0s)
+    t2 = time.perf_counter()
     rews = mean_h(orc, np.ascontiguousarray(rewss))  # :110
     Ybar_im1, w, rew_mean = orc.score_update(rews, Y0s, Ybar_i, float(alphas[i]), float(alphas_bar[i]),
                                              float(alphas_bar[i - 1]), temp, lp_demo=lp,
                                              rew_xref=env.rew_xref, literal=literal)  # :111-135
+    if timers is not None:
+        t3 = time.perf_counter()
+        for k, v in (("sample", t1 - t0), ("rollout", t2 - t1), ("score", t3 - t2)):
+            timers[k] = timers.get(k, 0.0) + v
     return rng, Ybar_im1, rew_mean, dict(Y0s=Y0s, rewss=rewss, rews=rews, weights=w, lp=lp)
 
 

@@ -1,7 +1,7 @@
 #!/bin/bash
 # a round's measurement pass: tests, bench line per single-GPU config, rocprofv3 kernel stats + PMC passes per config
-# usage (on the GPU box): TAG=r03 tools/gpu_round.sh [tests] [bench] [prof CONFIG...]   (summaries land in gpurun_out/profiles)
-TAG=${TAG:-r03}
+# usage (on the GPU box): TAG=r04 tools/gpu_round.sh [tests] [bench] [prof CONFIG...]   (summaries land in gpurun_out/profiles)
+TAG=${TAG:-r04}
 cd "$GRAFT_REPO_ROOT" || exit 1
 R=$GRAFT_REPO_ROOT; OUT=$R/gpurun_out; mkdir -p $OUT
 python __graft_entry__.py 2>&1 | tail -1
