@@ -195,22 +195,56 @@ def cpu_baseline(cfg, seconds_budget=15.0):
     ref_rec, ref_why = reference_baseline(cfg)
     port, fsub = port_baseline(cfg, seconds_budget)
     if ref_rec is not None:
-        ref_rec["port"] = {k: port[k] for k in ("value", "cores", "physical_cores", "phase_ms", "sample")}
+        ref_rec["port"] = {k: port[k] for k in ("value", "cores", "physical_cores", "host", "phase_ms", "sample")}
         return ref_rec, fsub
     port["reference_attempt"] = ref_why
     return port, fsub
+
+
+def usable_cpus():
+    """CPUs this process can actually keep busy: the affinity mask, capped by the cgroup's CPU quota (cpu.max =
+    "quota period": a container with 256 hardware threads visible and a quota of 16 runs 256 spinning OpenMP threads
+    into the throttle — measured on the bench box: one rollout 27 ms with 16 threads, 100-900 ms with 256).  Returns
+    (threads to use, a dict describing what was found)."""
+    import math
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    info = {"hardware_threads": os.cpu_count() or 1, "affinity": n, "cgroup_quota_cpus": None}
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:
+            q, per = f.read().split()[:2]
+        if q != "max":
+            info["cgroup_quota_cpus"] = float(q) / float(per)
+    except Exception:  # noqa: BLE001 — cgroup v1 / no cgroup
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:
+                q = float(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                per = float(f.read())
+            if q > 0:
+                info["cgroup_quota_cpus"] = q / per
+        except Exception:  # noqa: BLE001
+            pass
+    if info["cgroup_quota_cpus"]:
+        n = max(1, min(n, int(math.floor(info["cgroup_quota_cpus"] + 1e-9))))
+    if os.environ.get("OMP_NUM_THREADS"):
+        n = int(os.environ["OMP_NUM_THREADS"])
+    return n, info
 
 
 def port_baseline(cfg, seconds_budget=15.0):
     """The oracle (a port, NOT the JAX reference) timed on the host cores on a
     bounded sample of the same workload: consecutive reverse-diffusion steps of the config.  Also returns the
     op counter's F_sub for the config's model (the oracle may only be touched from this leg)."""
+    import ctypes as C
     import numpy as np
     from oracle import oracle as orc_mod
     from oracle import planner as op
     from mbd_hip.model import Model
     orc_mod.build()
     orc = orc_mod.Oracle("f32_omp")
+    threads, cpu_info = usable_cpus()
+    orc.lib.orc_set_threads.restype = C.c_int
+    threads = int(orc.lib.orc_set_threads(C.c_int(threads)))
     name, N, H, Nd, temp = cfg["env"], cfg["N"], cfg["H"], cfg["Nd"], cfg["temp"]
     compiled = os.path.join(ROOT, "model-based-diffusion_amd", "assets", "compiled")
     fsub = None
@@ -247,7 +281,6 @@ def port_baseline(cfg, seconds_budget=15.0):
         if time.time() - t0 > seconds_budget or i < 1:  # 10-15 s of host work, at most one whole plan
             break
     dt = time.time() - t0
-    threads = int(os.environ.get("OMP_NUM_THREADS", os.cpu_count() or 1))
     try:  # physical cores beside the hardware threads OpenMP uses (SMT siblings share the FP units)
         import psutil
         physical = psutil.cpu_count(logical=False)
@@ -260,10 +293,10 @@ def port_baseline(cfg, seconds_budget=15.0):
     # outside the three timed library phases plus the score phase's serial part is reported as `serial_share_upper_bound`
     serial = max(0.0, dt - sum(phases.values())) + phases.get("score", 0.0)
     return {"value": steps / dt, "unit": "diffusion-steps/sec", "cores": threads, "physical_cores": physical,
-            "kind": "port", "phase_ms": phase_ms, "serial_share_upper_bound": serial / dt,
+            "host": cpu_info, "kind": "port", "phase_ms": phase_ms, "serial_share_upper_bound": serial / dt,
             "sample": f"{steps} consecutive reverse-diffusion steps of {name} N={N} H={H} "
-                      f"(CPU oracle, OpenMP over candidates in sampler, rollout and weighted mean, {threads} threads, "
-                      f"{dt:.1f} s)"}, fsub
+                      f"(CPU oracle, OpenMP over candidates in sampler, rollout and weighted mean, {threads} threads = the CPUs "
+                      f"this container may use (affinity, cgroup quota), {dt:.1f} s)"}, fsub
 
 
 def main():

@@ -147,6 +147,21 @@ ORC_API float orc_erfinv_f32(float x) {
   return p * x;
 }
 
+/* threads of the OpenMP build (bench.py's cpu_baseline: the host's usable CPUs — cgroup quota, affinity — not its
+ * hardware thread count); returns the count in force (1 for the serial builds) */
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+ORC_API int orc_set_threads(int n) {
+#ifdef _OPENMP
+  if (n > 0) omp_set_num_threads(n);
+  return omp_get_max_threads();
+#else
+  (void)n;
+  return 1;
+#endif
+}
+
 /* jax.random.normal f32: sqrt(2) * erf_inv(uniform(nextafter(-1,0), 1)) */
 ORC_API void orc_normal(const uint32_t key[2], int impl, uint64_t begin, uint64_t count,
                         uint64_t size, float* out) {
