@@ -71,13 +71,38 @@ enum mbd_model_flags {
   MBD_FLAG_RESET_QUAT_RAW = 1, /* reset(): leave the noise-perturbed root quaternion un-normalised (humanoidrun.py:24-26
                                   perturbs all 7 root coordinates; whether kinematics.forward renormalises is unverified).
                                   Default 0: normalised.                                                          */
-  MBD_FLAG_PLANAR = 2          /* the model moves in the x-z plane (every hinge about the world y axis, slides and offsets
+  MBD_FLAG_PLANAR = 2,         /* the model moves in the x-z plane (every hinge about the world y axis, slides and offsets
                                   in the plane, no free joint: hopper, walker2d, halfcheetah, cartpole) and is simulated by
                                   the planar restatement of the same six stages — in-plane coordinates only — instead
                                   of the general 3-D arithmetic, whose float round-off leaks 1e-5..1e-3 out of the
                                   plane over a rollout.  Set by mbd_hip/mjcf.py when the model qualifies (planar=False
                                   keeps the 3-D path); a specification of its own for these models. */
+  /* ---- SPECIFICATION SWITCHES: the places where this engine had to guess at CODE level what Brax's positional
+   * pipeline does.  Default 0 = the specification every round so far ran; each bit selects the named
+   * alternative, in the checker and in the kernels alike (bit-exact against each other either way), so that a golden
+   * vector of the real reference flips a flag instead of forcing a rewrite (tools/compare_golden.py --search tries every
+   * combination).  Models with any of these bits run the general `spec` kernel instantiations (not the tuned ones). */
+  MBD_FLAG_CONTACT_AVG = 4,        /* several ACTIVE contacts on one link: the link's position correction (stage 4) — and,
+                                      with CONTACT6_JACOBI, its velocity change (stage 6) — is the AVERAGE over them
+                                      (sum * 1/n, n >= 2) instead of the sum; single contacts are untouched               */
+  MBD_FLAG_CONTACT6_JACOBI = 8,    /* stage (6), collisions.resolve_velocity: every contact of a link computes its impulse
+                                      from the SAME velocities (those stage (5) left) and the changes are added in
+                                      collider order — Brax vmaps its contacts — instead of one after the other, each
+                                      seeing what the previous left (Gauss-Seidel per link, the default)                  */
+  MBD_FLAG_FRICTION_VEL_BOUND = 16, /* stage (6) dynamic friction: |dv_t| = min(mu lambda_n / h, |v_t|) (Mueller et al.
+                                      2020, eq. 30, literally: the bound is a velocity) instead of
+                                      min(mu lambda_n / h * w_t, |v_t|) (the bound is an impulse)                         */
+  MBD_FLAG_RESTITUTION_MIN = 32,   /* stage (6): the literal min(-e vn_prev, 0) of eq. 34 (Brax's sign convention unknown;
+                                      with this engine's +z normal it makes elasticity a no-op) instead of max(.., 0)     */
+  MBD_FLAG_EULER_EXTRINSIC = 64,   /* joints with 2 or 3 hinge dofs: q composes as rotations about the FIXED joint-frame
+                                      axes (R = Rz(q2) Ry(q1) Rx(q0): gimbal axes Xc, Zp x Xc, Zp) instead of the moving
+                                      ones (R = Rx(q0) Ry(q1) Rz(q2): Xp, Zc x Xp, Zc) — forward kinematics at reset, the
+                                      angles / axes of stage (1) torques and stage (3) limits, observations               */
+  MBD_FLAG_GYROSCOPIC = 128        /* stage (2): angular acceleration includes -I^-1 (w x I w) (Mueller et al., eq. for
+                                      the velocity update); identically zero for isotropic tensors and planar models,
+                                      which ignore the bit                                                                */
 };
+#define MBD_SPEC_FLAGS (4 | 8 | 16 | 32 | 64 | 128)
 
 typedef struct mbd_model {
   /* sizes */

@@ -45,8 +45,9 @@ hipError_t launch_rollout_hot3d(int which, int rk, int nfr, int device, dim3 gri
                                 const RolloutParams& P);
 // the planar rollouts (mbd_planar.h; their own translation unit, mbd_planar.hip): lps lanes per candidate, the env's DPP
 // family, colliders per link, fl = the model's switches (1 springs | 2 slide limits | 4 elasticity), reward kind, n_frames
-// (0: run-time), no_fl: the general instantiation (lever MBD_NO_PLANAR_FLAGS)
-hipError_t launch_rollout_planar(int lps, int dpp_family, int max_col, int fl, int rk, int nfr, bool no_fl, int device,
+// (0: run-time), no_fl: the general instantiation (lever MBD_NO_PLANAR_FLAGS), spec: the model carries specification
+// switches (MBD_SPEC_FLAGS): the SPEC instantiation (16 lanes, shuffle exchange) reads them at run time
+hipError_t launch_rollout_planar(int lps, int dpp_family, int max_col, int fl, int rk, int nfr, bool no_fl, bool spec, int device,
                                  dim3 grid, dim3 block, size_t lds, hipStream_t stream, const RolloutParams& P);
 // fam: 0 the humanoid family, 1 ant (mbd_pk2.h)
 hipError_t launch_rollout_pk2(int fam, int maxcol, int rk, int nfr, int wpe, int device, dim3 grid, dim3 block, size_t lds,

@@ -73,9 +73,14 @@ __device__ __forceinline__ void pl_qupdate(float& w, float& y, float dth) {
 // twice over NFR / 2 substeps in line instead of NFR / 4 times over four plus a remainder loop: every iteration saved is
 // a taken branch (hopper, n_frames = 20: 7 -> 2 per control step, +2.7 % at N = 512; the in-line body stays under
 // ~30 KB — the humanoid's seven substeps in line, 39 KB, lost 1.9 %).
-template <int LPS, int MAXCOL, int D0 = 0, int D1 = 0, int FL = -1, int RK = -1, int NFR = 0>
+// SPEC: the model's specification switches that exist in the plane (mbd_model_flags: contact_avg, contact6_jacobi,
+// friction_vel_bound, restitution_min — DESIGN.md §9) are read at run time and honoured as the checker's planar
+// restatement states them; one general instantiation is built with it (models carrying such a bit run there), every other one
+// compiles the default specification in.
+template <int LPS, int MAXCOL, int D0 = 0, int D1 = 0, int FL = -1, int RK = -1, int NFR = 0, bool SPEC = false>
 __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   static_assert(NFR % 2 == 0, "NFR: two iterations of NFR / 2");
+  static_assert(!SPEC || (D0 == 0 && FL < 0), "SPEC: the general shuffle-exchange instantiation");
   constexpr bool DPP = D0 != 0;
   constexpr int NSLOT = DPP ? (D1 != 0 ? 2 : 1) : kMaxChildren;
   rollout_progress(P);
@@ -191,6 +196,9 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   const int rkind = RK >= 0 ? RK : M->reward_kind;
   const float rp0 = M->reward_params[0], rp1 = M->reward_params[1];
   const float dt_ctrl = M->dt * (float)nfr;
+  const int spec = SPEC ? (M->flags & MBD_SPEC_FLAGS) : 0;  // (wave-uniform; 0 elsewhere: the tests below fold away)
+  const bool sp_avg = (spec & MBD_FLAG_CONTACT_AVG) != 0, sp_jac = (spec & MBD_FLAG_CONTACT6_JACOBI) != 0;
+  const bool sp_fvel = (spec & MBD_FLAG_FRICTION_VEL_BOUND) != 0, sp_rmin = (spec & MBD_FLAG_RESTITUTION_MIN) != 0;
 
   // ---- exchange -----------------------------------------------------------------------------------------
   auto from_parent = [&](float v) -> float {  // the value of v in the parent's lane (0 for a world parent)
@@ -464,6 +472,15 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
             cposx[j] = posx; cposz[j] = posz; cdlam[j] = dlam; cact[j] = active;
           }
         }
+        if constexpr (SPEC && MAXCOL > 0) {
+          if (sp_avg) {  // the average over the link's active contacts (two or more; one: untouched)
+            int n_act = 0;
+#pragma unroll
+            for (int j = 0; j < MAXCOL; ++j) n_act += cact[j] ? 1 : 0;
+            const float inv_n = 1.0f / (float)(n_act > 1 ? n_act : 1);
+            cdx = n_act >= 2 ? cdx * inv_n : cdx; cdz = n_act >= 2 ? cdz * inv_n : cdz; cdth = n_act >= 2 ? cdth * inv_n : cdth;
+          }
+        }
         px = px + cdx; pz = pz + cdz;
         pl_qupdate<true>(qw, qy, cdth);
       }
@@ -478,10 +495,12 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       }
       // ---- (6) collisions.resolve_velocity (sequential per link) ---------------------------------------------
       if constexpr (MAXCOL > 0) {
+        const float vx6 = vx, vz6 = vz, om6 = om;  // (SPEC, contact6_jacobi: what every contact of the link sees)
 #pragma unroll
         for (int j = 0; j < MAXCOL; ++j) {
           const float rcx = cposx[j] - px, rcz = cposz[j] - pz;
-          const float vptx = ffma(om, rcz, vx), vptz = ffma(-om, rcx, vz);
+          const float svx = (SPEC && sp_jac) ? vx6 : vx, svz = (SPEC && sp_jac) ? vz6 : vz, som = (SPEC && sp_jac) ? om6 : om;
+          const float vptx = ffma(som, rcz, svx), vptz = ffma(-som, rcx, svz);
           float vn_prev = 0.0f;
           if (FL >= 0 ? (FL & 4) != 0 : elast != 0.0f) vn_prev = ffma(-om_old, rcx, vz_old);  // (wave-uniform; with e = 0 the term is exactly 0)
           // (in the plane the slip direction is the sign of vptx: no normalising division, lever arm rcz)
@@ -490,14 +509,25 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
           const float wn = ffma(icn, rcx, im_c);
           const float wt = ffma(rcz, rcz * iy_c, im_c);
           const float rest = -elast * vn_prev;
-          const float dvn = fmax_(rest, 0.0f) - vptz;
+          const float dvn = ((SPEC && sp_rmin) ? fmin_(rest, 0.0f) : fmax_(rest, 0.0f)) - vptz;
           const float jt_max = (mu * cdlam[j]) * inv_dt;
-          const float dvt = fmin_(jt_max * wt, vtn);
+          const float dvt = fmin_((SPEC && sp_fvel) ? jt_max : jt_max * wt, vtn);
           const f2 q_nt = div2_sp_(mk2(dvn, dvt), mk2(wn, wt));
           const float Pix = -__builtin_copysignf(q_nt.y, vptx), Piz = q_nt.x;  // friction opposes the slip
           const float nvx = ffma(im_c, Pix, vx), nvz = ffma(im_c, Piz, vz);
           const float nom = om + pl_cross(rcx, rcz, Pix, Piz) * iy_c;
           vx = cact[j] ? nvx : vx; vz = cact[j] ? nvz : vz; om = cact[j] ? nom : om;
+        }
+        if constexpr (SPEC) {
+          if (sp_jac && sp_avg) {  // the average of the link's velocity changes: v6 + (v - v6) / n
+            int n_act = 0;
+#pragma unroll
+            for (int j = 0; j < MAXCOL; ++j) n_act += cact[j] ? 1 : 0;
+            const float inv_n = 1.0f / (float)(n_act > 1 ? n_act : 1);
+            vx = n_act >= 2 ? ffma(vx - vx6, inv_n, vx6) : vx;
+            vz = n_act >= 2 ? ffma(vz - vz6, inv_n, vz6) : vz;
+            om = n_act >= 2 ? ffma(om - om6, inv_n, om6) : om;
+          }
         }
       }
     };

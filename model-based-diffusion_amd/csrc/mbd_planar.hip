@@ -9,9 +9,10 @@
 
 namespace mbd {
 
-hipError_t launch_rollout_planar(int lps, int dpp_family, int max_col, int fl, int rk, int nfr, bool no_fl, int device,
+hipError_t launch_rollout_planar(int lps, int dpp_family, int max_col, int fl, int rk, int nfr, bool no_fl, bool spec, int device,
                                  dim3 grid, dim3 block, size_t lds, hipStream_t stream, const RolloutParams& P) {
 #define PL(...) return launch_rollout_kernel(rollout_planar_kernel<__VA_ARGS__>, device, grid, block, lds, stream, P)
+  if (spec) PL(16, 2, 0, 0, -1, -1, 0, true);  // specification switches at run time
   // (... the reward kind: cartpole, hopper, walker2d, halfcheetah; and n_frames, for the values the built-in models have:
   // NFR.  Not for halfcheetah, n_frames = 16: 2 x 8 in line measured -0.2 %, 4 x 4 with a constant trip count -0.9 % — its
   // substep compiles to 399 / 402 instructions instead of 398)

@@ -24,7 +24,7 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-from .model import (MAX_ACT, MAX_COL, MAX_LINKS, MAX_Q, MAX_TRACK, Model, REWARD_KINDS)
+from .model import (MAX_ACT, MAX_COL, MAX_LINKS, MAX_Q, MAX_TRACK, Model, REWARD_KINDS, SPEC_MASK)
 
 # defaults of brax.io.mjcf.load for <custom><numeric> entries that are absent (recollection)
 _CUSTOM_DEFAULTS = {
@@ -271,7 +271,8 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
          track_names: Sequence[str] = (), reset_noise: float = 0.0,
          reward_params: Sequence[float] = (), dt_override: Optional[float] = None,
          init_q_offset: Sequence[float] = (), gear_override: Sequence[float] = (),
-         passive_joint_forces: bool = True, reset_quat_raw: bool = False, planar: Optional[bool] = None) -> Model:
+         passive_joint_forces: bool = True, reset_quat_raw: bool = False, planar: Optional[bool] = None,
+         spec_flags: int = 0) -> Model:
     """Compile an MJCF file. ``n_frames`` is the env's physics substeps per control step
     (humanoidrun.py:17 -> 7, humanoidtrack.py:46 -> 5, hopper.py:18 -> 20).
 
@@ -284,6 +285,9 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
       gear_override         the env class's replacement of sys.actuator.gear (brax ant / half_cheetah).
       planar                None: set MBD_FLAG_PLANAR when the model qualifies (see ``is_planar``); False: keep
                             the general 3-D arithmetic for a planar model.
+      spec_flags            the CODE-level guesses as flag bits (model.SPEC_FLAGS / model.spec_bits: contact_avg,
+                            contact6_jacobi, friction_vel_bound, restitution_min, euler_extrinsic, gyroscopic;
+                            include/mbd_hip.h mbd_model_flags): checker and kernels honour them alike.
     Reward-side switches live in reward_params (ant: [5] = terminate_when_unhealthy)."""
     root = ET.parse(path).getroot()
     comp = root.find("compiler")
@@ -526,7 +530,8 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
     F.update(
         n_links=L, n_q=nq, n_qd=nqd, n_act=len(act_link), n_col=len(col_link), n_track=len(track),
         n_frames=int(n_frames), reward_kind=REWARD_KINDS.get(env_name, 0), iso_inertia=int(iso),
-        flags=int(1 if reset_quat_raw else 0),  # (MBD_FLAG_PLANAR is added below, once the model is complete)
+        # (MBD_FLAG_PLANAR is added below, once the model is complete; spec_flags: the specification switches, model.SPEC_FLAGS)
+        flags=int(1 if reset_quat_raw else 0) | (int(spec_flags) & SPEC_MASK),
         dt=np.float32(dt), vel_fac=np.float32(math.exp(custom["vel_damping"] * dt)),
         ang_fac=np.float32(math.exp(custom["ang_damping"] * dt)),
         joint_scale_pos=np.float32(custom["joint_scale_pos"]),

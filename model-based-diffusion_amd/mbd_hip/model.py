@@ -22,6 +22,23 @@ LINK_STATE = 13
 REWARD_KINDS = {"humanoidrun": 0, "hopper": 1, "halfcheetah": 2, "humanoidtrack": 3, "walker2d": 1,
                 "humanoidstandup": 4, "cartpole": 5, "ant": 6}
 
+# mbd_model_flags (include/mbd_hip.h).  The SPEC_* bits are the specification switches of DESIGN.md §9: code-level guesses
+# about Brax's positional pipeline, default 0; tools/compare_golden.py --search tries every combination against a golden.
+FLAG_RESET_QUAT_RAW, FLAG_PLANAR = 1, 2
+SPEC_FLAGS = {"contact_avg": 4, "contact6_jacobi": 8, "friction_vel_bound": 16, "restitution_min": 32,
+              "euler_extrinsic": 64, "gyroscopic": 128}
+SPEC_MASK = sum(SPEC_FLAGS.values())
+
+
+def spec_bits(*names: str) -> int:
+    """The flag word of the named specification switches: spec_bits("contact_avg", "contact6_jacobi") -> 12."""
+    return sum(SPEC_FLAGS[n] for n in names)
+
+
+def spec_names(flags: int):
+    return [n for n, b in SPEC_FLAGS.items() if flags & b]
+
+
 _L, _A, _K, _T = MAX_LINKS, MAX_ACT, MAX_COL, MAX_TRACK
 _f, _i = C.c_float, C.c_int32
 
@@ -88,6 +105,16 @@ class Model:
     @property
     def init_q(self) -> np.ndarray:
         return np.asarray(self.fields["init_q"], np.float32)[: self.q_size()].copy()
+
+    def with_spec(self, flags: int) -> "Model":
+        """A copy of the model whose specification switches (SPEC_FLAGS bits) are ``flags``; everything else unchanged."""
+        f = dict(self.fields)
+        f["flags"] = (int(f.get("flags", 0)) & ~SPEC_MASK) | (int(flags) & SPEC_MASK)
+        m = Model(f, self.link_names, self.actuator_names, self.env_name)
+        for extra in ("masses", "inertias"):
+            if hasattr(self, extra):
+                setattr(m, extra, getattr(self, extra))
+        return m
 
     def to_struct(self) -> MbdModel:
         s = MbdModel()

@@ -151,6 +151,47 @@ static void joint_frames(const mbd_model_t* m, int l, const xf_t* P, const xf_t*
   real n[3];
   sp_cross3(f->Zc, f->Xp, n);
   sp_scale3(n, inv, f->ax[1]);
+  if ((m->flags & MBD_FLAG_EULER_EXTRINSIC) && m->n_rot[l] >= 2) {
+    /* R_rel = Rz(c) Ry(b) Rx(a) (rotations about the FIXED joint-frame axes).  Its transpose is Rx(-a) Ry(-b) Rz(-c): the
+     * decomposition above with the roles of parent and child frames exchanged yields (-a, -b, -c), and the relative
+     * angular velocity of the child is a' Xc + b' (Zp x Xc)/cos b + c' Zp — the same expressions with p <-> c. */
+    real sb2 = sp_clip(sp_dot3(f->Zp, f->Xc), R(-1), R(1));
+    real cb2e = sp_fma(-sb2, sb2, R(1));
+    real cbe = sp_sqrt_floor(cb2e);
+    real inve = sp_div(R(1), cbe + R(1e-10));
+    f->ang[0] = -sp_angle_unit(-sp_dot3(f->Zp, f->Yc) * inve, sp_dot3(f->Zp, f->Zc) * inve);
+    f->ang[1] = -sp_angle_unit(sb2, cbe);
+    f->ang[2] = -sp_angle_unit(-sp_dot3(f->Yp, f->Xc) * inve, sp_dot3(f->Xp, f->Xc) * inve);
+    sp_copy3(f->Xc, f->ax[0]);
+    sp_copy3(f->Zp, f->ax[2]);
+    sp_cross3(f->Zp, f->Xc, n);
+    sp_scale3(n, inve, f->ax[1]);
+  }
+}
+
+/* body-frame inertia tensor (xx yy zz xy xz yz) from the model's inverse: adjugate / determinant of the symmetric 3x3
+ * (MBD_FLAG_GYROSCOPIC; the kernels evaluate the same expressions once per env) */
+static void inertia_from_inverse(const real b[6], real I[6]) {
+  const real xx = b[0], yy = b[1], zz = b[2], xy = b[3], xz = b[4], yz = b[5];
+  const real c0 = yy * zz - yz * yz, c1 = xz * yz - xy * zz, c2 = xy * yz - xz * yy;
+  const real det = (xx * c0 + xy * c1) + xz * c2;
+  const real id = R(1) / det;
+  I[0] = c0 * id; I[1] = (xx * zz - xz * xz) * id; I[2] = (xx * yy - xy * xy) * id;
+  I[3] = c1 * id; I[4] = c2 * id; I[5] = (xy * xz - xx * yz) * id;
+}
+/* the gyroscopic angular acceleration -I^-1 (w x I w), evaluated in the body frame of orientation r and rotated back */
+static void gyro_accel(const real ib[6], const real r[4], const real w[3], real out[3]) {
+  real I[6], wb[3], Lb[3], g[3], ab[3];
+  inertia_from_inverse(ib, I);
+  sp_irot(w, r, wb);
+  Lb[0] = sp_fma(I[4], wb[2], sp_fma(I[3], wb[1], I[0] * wb[0]));
+  Lb[1] = sp_fma(I[5], wb[2], sp_fma(I[1], wb[1], I[3] * wb[0]));
+  Lb[2] = sp_fma(I[2], wb[2], sp_fma(I[5], wb[1], I[4] * wb[0]));
+  sp_cross3(wb, Lb, g);
+  ab[0] = -sp_fma(ib[4], g[2], sp_fma(ib[3], g[1], ib[0] * g[0]));
+  ab[1] = -sp_fma(ib[5], g[2], sp_fma(ib[1], g[1], ib[3] * g[0]));
+  ab[2] = -sp_fma(ib[2], g[2], sp_fma(ib[5], g[1], ib[4] * g[0]));
+  sp_rot(ab, r, out);
 }
 
 /* one angular positional correction: rotate child by +e, parent by -e, split by angular inverse
@@ -318,6 +359,12 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_copy3(fc_v[l], av); sp_copy3(fc_w[l], aw);
     for (int c = l + 1; c < L; ++c)
       if (m->parent[c] == l) { sp_add3(av, fp_v[c], av); sp_add3(aw, fp_w[c], aw); }
+    if ((m->flags & MBD_FLAG_GYROSCOPIC) && !m->iso_inertia) { /* from the pose and velocity the substep started with */
+      real ib[6], gy[3];
+      for (int k = 0; k < 6; ++k) ib[k] = R(m->inv_inertia[l][k]);
+      gyro_accel(ib, x[l].r, xd[l].w, gy);
+      sp_add3(aw, gy, aw);
+    }
     sp_copy3(av, acc_dump[l].v); sp_copy3(aw, acc_dump[l].w);
     for (int i = 0; i < 3; ++i) {
       xd[l].v[i] = sp_fma(av[i] + R(m->gravity[i]), dt, R(m->vel_fac) * xd[l].v[i]);
@@ -400,9 +447,12 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
       real s = sp_copysign(R(2), qe[0]);
       sp_set3(e, s * qe[1], s * qe[2], s * qe[3]);
     } else {
-      const real* A = nr == 1 ? f.Xc : f.Xp;
-      const real* B = nr == 1 ? f.Xp : f.Yc;
-      real sc = nr == 1 ? R(1) : (nr == 2 ? sp_dot3(f.Xp, f.Yc) : R(0));
+      /* (2 dofs: the child's Y stays perpendicular to the parent's X; under MBD_FLAG_EULER_EXTRINSIC — R = Ry Rx — the
+       * parent's Y stays perpendicular to the child's X instead) */
+      const int ext = (m->flags & MBD_FLAG_EULER_EXTRINSIC) && nr == 2;
+      const real* A = nr == 1 ? f.Xc : (ext ? f.Yp : f.Xp);
+      const real* B = nr == 1 ? f.Xp : (ext ? f.Xc : f.Yc);
+      real sc = nr == 1 ? R(1) : (nr == 2 ? sp_dot3(A, B) : R(0));
       real cr[3];
       sp_cross3(A, B, cr);
       sp_scale3(cr, sc, e);
@@ -490,7 +540,14 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     sp_axpy3(in[l].inv_mass, Pimp, cd_p[l]);
     sp_cross3(rc, Pimp, mom); iinv_apply(&in[l], mom, t); sp_add3(cd_th[l], t, cd_th[l]);
   }
+  int n_act[MBD_MAX_LINKS];
+  memset(n_act, 0, sizeof(n_act));
+  for (int k = 0; k < m->n_col; ++k) n_act[m->col_link[k]] += con[k].active ? 1 : 0;
   for (int l = 0; l < L; ++l) { /* all links: zero corrections where there is no collider */
+    if ((m->flags & MBD_FLAG_CONTACT_AVG) && n_act[l] >= 2) { /* the average over the link's active contacts */
+      const real inv_n = R(1) / (real)n_act[l];
+      sp_scale3(cd_p[l], inv_n, cd_p[l]); sp_scale3(cd_th[l], inv_n, cd_th[l]);
+    }
     sp_add3(x[l].p, cd_p[l], x[l].p);
     sp_qrotvec(x[l].r, cd_th[l]);
   }
@@ -508,12 +565,16 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
   dump_stage(4, L, x, xd); /* (5) */
   /* ---- (6) collisions.resolve_velocity: restitution + dynamic friction at active contacts */
   for (int l = 0; l < L; ++l) inert_refresh(&in[l], x[l].r);
+  const int jacobi6 = (m->flags & MBD_FLAG_CONTACT6_JACOBI) != 0;
+  mo_t xd6[MBD_MAX_LINKS]; /* the velocities stage (5) left: what every contact sees under MBD_FLAG_CONTACT6_JACOBI */
+  for (int l = 0; l < L; ++l) xd6[l] = xd[l];
   for (int k = 0; k < m->n_col; ++k) {
     if (!con[k].active) continue;
     const int l = m->col_link[k];
+    const mo_t* see = jacobi6 ? &xd6[l] : &xd[l]; /* (default: what the link's previous contacts left — Gauss-Seidel) */
     real rc[3], t[3], vpt[3], vprev[3];
     sp_sub3(con[k].pos, x[l].p, rc);
-    sp_cross3(xd[l].w, rc, t); sp_add3(xd[l].v, t, vpt);
+    sp_cross3(see->w, rc, t); sp_add3(see->v, t, vpt);
     sp_cross3(xd_prev[l].w, rc, t); sp_add3(xd_prev[l].v, t, vprev);
     real vn = vpt[2], vn_prev = vprev[2];
     real vt[3] = {vpt[0], vpt[1], R(0)};
@@ -528,16 +589,26 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
     /* restitution (Mueller et al. 2020, eq. 34, written for a normal that points OUT of the floor, +z): an approaching
      * contact has vn_prev < 0, and the velocity after the solve is max(-e vn_prev, 0).  (Until round 3 this read
      * min(...): with this normal that term is never positive and the elasticity did nothing — found by
-     * tests/test_oracle_invariants.py::test_restitution; every built-in model has e = 0, for which both forms give 0.) */
-    real dvn = sp_max(rest, R(0)) - vn;
-    real jt_max = (mu * con[k].dlam) * inv_dt; /* friction impulse bound mu * lambda_n / h */
-    real dvt = sp_min(jt_max * wt, vtn);
+     * tests/test_oracle_invariants.py::test_restitution; every built-in model has e = 0, for which both forms give 0.
+     * MBD_FLAG_RESTITUTION_MIN keeps the literal min(): which sign convention Brax's normal has is unpinned.) */
+    real dvn = ((m->flags & MBD_FLAG_RESTITUTION_MIN) ? sp_min(rest, R(0)) : sp_max(rest, R(0))) - vn;
+    real jt_max = (mu * con[k].dlam) * inv_dt; /* friction bound mu * lambda_n / h: an impulse (default) or a velocity */
+    real dvt = sp_min((m->flags & MBD_FLAG_FRICTION_VEL_BOUND) ? jt_max : jt_max * wt, vtn);
     real jn = sp_div(dvn, wn), jt = -sp_div_pos(dvt, wt);
     real Pimp[3] = {dir[0] * jt, dir[1] * jt, jn};
-    sp_axpy3(in[l].inv_mass, Pimp, xd[l].v);
+    sp_axpy3(in[l].inv_mass, Pimp, xd[l].v); /* (Jacobi: the changes are added in collider order, onto the running value) */
     real mom[3];
     sp_cross3(rc, Pimp, mom); iinv_apply(&in[l], mom, t); sp_add3(xd[l].w, t, xd[l].w);
   }
+  if (jacobi6 && (m->flags & MBD_FLAG_CONTACT_AVG))
+    for (int l = 0; l < L; ++l)
+      if (n_act[l] >= 2) { /* the average of the link's velocity changes: v6 + (v - v6) / n */
+        const real inv_n = R(1) / (real)n_act[l];
+        for (int i = 0; i < 3; ++i) {
+          xd[l].v[i] = sp_fma(xd[l].v[i] - xd6[l].v[i], inv_n, xd6[l].v[i]);
+          xd[l].w[i] = sp_fma(xd[l].w[i] - xd6[l].w[i], inv_n, xd6[l].w[i]);
+        }
+      }
   dump_stage(5, L, x, xd); /* (6) */
 }
 
@@ -728,15 +799,22 @@ ORC_API void orc_forward(const mbd_model_t* m, const float* q, const float* qd, 
         sp_axpy3(R(ql[k]), a, jpos);
         sp_axpy3(R(qdl[k]), a, sv);
       }
+      const int ext = (m->flags & MBD_FLAG_EULER_EXTRINSIC) && nr >= 2;
       for (int k = 0; k < nr; ++k) {
         real a[3] = {m->rot_axis[l][k][0], m->rot_axis[l][k][1], m->rot_axis[l][k][2]}, ac[3];
-        sp_rot(a, jrot, ac);
-        sp_axpy3(R(qdl[ns + k]), ac, wrel);
         real h = R(0.5) * R(ql[ns + k]);
         real s, c;
         sp_sincos(h, &s, &c);
         real qk[4] = {c, s * a[0], s * a[1], s * a[2]}, t[4];
-        sp_qmul(jrot, qk, t);
+        if (ext) { /* about the FIXED axes: R <- R_k R, and what was accumulated so far turns with R_k */
+          sp_rot(wrel, qk, ac); sp_copy3(ac, wrel);
+          sp_axpy3(R(qdl[ns + k]), a, wrel);
+          sp_qmul(qk, jrot, t);
+        } else {
+          sp_rot(a, jrot, ac);
+          sp_axpy3(R(qdl[ns + k]), ac, wrel);
+          sp_qmul(jrot, qk, t);
+        }
         memcpy(jrot, t, sizeof(t));
       }
       real jp[3] = {m->joint_pos[l][0], m->joint_pos[l][1], m->joint_pos[l][2]}, t[3];

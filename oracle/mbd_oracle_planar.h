@@ -285,7 +285,14 @@ static void substep_planar(const mbd_model_t* m, pxf_t* x, pmo_t* xd, const real
       cdx[l] = sp_fma(K[l].im, Pix, cdx[l]); cdz[l] = sp_fma(K[l].im, Piz, cdz[l]); cdth[l] = cdth[l] + dth;
     }
   }
+  int n_act[MBD_MAX_LINKS];
+  for (int l = 0; l < L; ++l) n_act[l] = 0;
+  for (int k = 0; k < m->n_col; ++k) n_act[m->col_link[k]] += act[k] ? 1 : 0;
   for (int l = 0; l < L; ++l) {
+    if ((m->flags & MBD_FLAG_CONTACT_AVG) && n_act[l] >= 2) { /* the average over the link's active contacts */
+      const real inv_n = R(1) / (real)n_act[l];
+      cdx[l] = cdx[l] * inv_n; cdz[l] = cdz[l] * inv_n; cdth[l] = cdth[l] * inv_n;
+    }
     x[l].px = x[l].px + cdx[l]; x[l].pz = x[l].pz + cdz[l];
     pl_qupdate(&x[l].qw, &x[l].qy, cdth[l], 1);
   }
@@ -301,12 +308,17 @@ static void substep_planar(const mbd_model_t* m, pxf_t* x, pmo_t* xd, const real
     xd[l].om = dqy * sp_copysign(two_inv_dt, dqw);
   }
   PL_DUMP(4);
-  /* ---- (6) collisions.resolve_velocity (sequential per link) ------------------------------------------ */
+  /* ---- (6) collisions.resolve_velocity (sequential per link; MBD_FLAG_CONTACT6_JACOBI: every contact of a link from the
+   * velocities stage (5) left, the changes added in collider order) ------------------------------------------------- */
+  const int jacobi6 = (m->flags & MBD_FLAG_CONTACT6_JACOBI) != 0;
+  pmo_t xd6[MBD_MAX_LINKS];
+  for (int l = 0; l < L; ++l) xd6[l] = xd[l];
   for (int k = 0; k < m->n_col; ++k) {
     if (!act[k]) continue;
     const int l = m->col_link[k];
+    const pmo_t* see = jacobi6 ? &xd6[l] : &xd[l];
     const real rcx = cposx[k] - x[l].px, rcz = cposz[k] - x[l].pz;
-    const real vptx = sp_fma(xd[l].om, rcz, xd[l].vx), vptz = sp_fma(-xd[l].om, rcx, xd[l].vz);
+    const real vptx = sp_fma(see->om, rcz, see->vx), vptz = sp_fma(-see->om, rcx, see->vz);
     const real vn_prev = sp_fma(-xd_old[l].om, rcx, xd_old[l].vz);
     /* in the plane the slip direction is a SIGN (the 3-D form's vt / (|vt| + 1e-10) is +-1 up to 1e-10 / |vt|):
      * no division, the tangential lever arm is rcz itself */
@@ -315,15 +327,23 @@ static void substep_planar(const mbd_model_t* m, pxf_t* x, pmo_t* xd, const real
     const real wn = sp_fma(icn, rcx, K[l].im);
     const real wt = sp_fma(rcz, rcz * K[l].iy, K[l].im);
     const real rest = -R(m->elasticity) * vn_prev;
-    const real dvn = sp_max(rest, R(0)) - vptz;
+    const real dvn = ((m->flags & MBD_FLAG_RESTITUTION_MIN) ? sp_min(rest, R(0)) : sp_max(rest, R(0))) - vptz;
     const real jt_max = (mu * cdlam[k]) * inv_dt;
-    const real dvt = sp_min(jt_max * wt, vtn);
+    const real dvt = sp_min((m->flags & MBD_FLAG_FRICTION_VEL_BOUND) ? jt_max : jt_max * wt, vtn);
     const real jn = sp_div(dvn, wn);
     const real Pix = -sp_copysign(sp_div_pos(dvt, wt), vptx), Piz = jn; /* friction opposes the slip */
     xd[l].vx = sp_fma(K[l].im, Pix, xd[l].vx);
     xd[l].vz = sp_fma(K[l].im, Piz, xd[l].vz);
     xd[l].om = xd[l].om + pl_cross(rcx, rcz, Pix, Piz) * K[l].iy;
   }
+  if (jacobi6 && (m->flags & MBD_FLAG_CONTACT_AVG))
+    for (int l = 0; l < L; ++l)
+      if (n_act[l] >= 2) { /* the average of the link's velocity changes: v6 + (v - v6) / n */
+        const real inv_n = R(1) / (real)n_act[l];
+        xd[l].vx = sp_fma(xd[l].vx - xd6[l].vx, inv_n, xd6[l].vx);
+        xd[l].vz = sp_fma(xd[l].vz - xd6[l].vz, inv_n, xd6[l].vz);
+        xd[l].om = sp_fma(xd[l].om - xd6[l].om, inv_n, xd6[l].om);
+      }
   PL_DUMP(5);
 #undef PL_DUMP
 }

@@ -2,10 +2,19 @@
 STAGE and name the first stage and link whose pose or velocity differs from Brax's by more than the tolerance —
 i.e. which of DESIGN.md §9's guesses is wrong — after first comparing the compiled system (masses, inertias).
 
-    python tools/compare_golden.py tests/golden/golden_humanoidrun_N64_H50.npz [--tol 1e-5]
+    python tools/compare_golden.py tests/golden/golden_humanoidrun_N64_H50.npz [--tol 1e-5] [--flags N] [--search]
 
-Exit code 0: every stage within tolerance; 1: a mismatch was reported; 2: the file has no stage records.
-Importable: compare(path, tol) -> list of report lines, first_mismatch (None or (stage, link, quantity, err))."""
+--flags N   replay under the specification switches N (include/mbd_hip.h mbd_model_flags / mbd_hip.model.SPEC_FLAGS:
+            contact_avg 4, contact6_jacobi 8, friction_vel_bound 16, restitution_min 32, euler_extrinsic 64, gyroscopic 128)
+--search    replay under EVERY combination of the six switches and rank them: most stages within tolerance first, then the
+            smallest error at the first mismatching stage, then the fewest switches — the line to read is the first one; a
+            winner other than "default" names the code-level guesses of DESIGN.md §9 that Brax decides the other way, and
+            the model is then recompiled with that flag word (mjcf.load(spec_flags=...)): no kernel or checker rewrite.
+
+Exit code 0: every stage within tolerance (--search: under the best combination); 1: a mismatch was reported; 2: the file
+has no stage records.
+Importable: compare(path, tol, flags=0) -> list of report lines, first_mismatch (None or (stage, link, quantity, err));
+search(path, tol) -> list of (flags, names, first_mismatch, stages_ok, err_at_first) best first."""
 import os
 import sys
 
@@ -34,14 +43,14 @@ def _state(g, prefix):
                           axis=1).astype(np.float32)
 
 
-def compare(path, tol=1e-5):
+def compare(path, tol=1e-5, flags=0):
     from mbd_hip.model import Model
     from oracle import oracle as orc_mod
     import ctypes as C
     g = np.load(path)
     name = os.path.basename(path).split("_")[1]
     with open(os.path.join(ROOT, "model-based-diffusion_amd", "assets", "compiled", f"{name}.json")) as f:
-        m = Model.from_json(f.read())
+        m = Model.from_json(f.read()).with_spec(flags)
     ms = m.to_struct()
     L = m.n_links
     lines, first = [], None
@@ -77,6 +86,14 @@ def compare(path, tol=1e-5):
                 if f"{prefix}stage_4_contact_position_contact_dist" in g else -1
             lines.append(f"---- substep from the settled state ({n_touch if n_touch >= 0 else '?'} penetrating contacts)")
         first = _compare_substep(g, prefix, m, ms, L, orc, tol, lines, first)
+    if "bounce_vz" in g:  # record (C): does a ball with elasticity e come back up?
+        vz = np.asarray(g["bounce_vz"], np.float64)
+        hit = int(np.argmin(vz[:400]))
+        ratio = float(vz[hit:hit + 30].max() / -vz[hit]) if vz[hit] < 0 else 0.0
+        e = float(g["bounce_elasticity"])
+        verdict = ("max(-e vn, 0): this repo's default" if abs(ratio - e) < 0.1 else
+                   ("min(-e vn, 0): MBD_FLAG_RESTITUTION_MIN (32)" if ratio < 0.1 else "neither form"))
+        lines.append(f"restitution: rebound / impact speed = {ratio:.3f} at elasticity {e:g} -> {verdict}")
     if first is not None:
         st = first[0]
         lines.append(f"FIRST MISMATCH: stage {st}, link {first[1]} ({m.link_names[first[1]] if 0 <= first[1] < L else '?'}), "
@@ -131,8 +148,34 @@ def _compare_substep(g, prefix, m, ms, L, orc, tol, lines, first):
     return first
 
 
+def search(path, tol=1e-5):
+    """compare() under every combination of the specification switches; best first (see the module docstring)."""
+    from mbd_hip.model import SPEC_FLAGS, spec_names
+    bits = sorted(SPEC_FLAGS.values())
+    order = ["sys"] + [p + s for p in ("", "contact:") for s in STAGES + ["end_of_substep"]]
+    rows = []
+    for mask in range(1 << len(bits)):
+        flags = sum(b for k, b in enumerate(bits) if mask >> k & 1)
+        lines, first = compare(path, tol, flags)
+        if first is not None and first[0] == "none":
+            return [(0, [], first, 0, 0.0)]
+        ok = len(order) if first is None else (order.index(first[0]) if first[0] in order else 0)
+        rows.append((flags, spec_names(flags), first, ok, 0.0 if first is None else first[3]))
+    rows.sort(key=lambda r: (-r[3], r[4], bin(r[0]).count("1"), r[0]))
+    return rows
+
+
 if __name__ == "__main__":
     tol = float(sys.argv[sys.argv.index("--tol") + 1]) if "--tol" in sys.argv else 1e-5
-    lines, first = compare(sys.argv[1], tol)
+    if "--search" in sys.argv:
+        rows = search(sys.argv[1], tol)
+        for flags, names, first, ok, err in rows[:12]:
+            where = "all stages within tolerance" if first is None else f"first mismatch {first[0]} link {first[1]} {first[2]} err {err:.3g}"
+            print(f"flags {flags:3d} [{', '.join(names) or 'default'}]: {where}")
+        best = rows[0]
+        print(f"BEST: flags {best[0]} ({', '.join(best[1]) or 'the default specification'})")
+        sys.exit(0 if best[2] is None else (2 if best[2][0] == "none" else 1))
+    flags = int(sys.argv[sys.argv.index("--flags") + 1]) if "--flags" in sys.argv else 0
+    lines, first = compare(sys.argv[1], tol, flags)
     print("\n".join(lines))
     sys.exit(0 if first is None else (2 if first[0] == "none" else 1))

@@ -13,7 +13,9 @@ Two kinds of records go into golden_<env>_N<N>_H<H>.npz:
      collisions.resolve_position, integrator.project_xd and collisions.resolve_velocity, plus the compiled `sys`
      (link masses, inertias, joint frames, actuator gears, the <custom> scalars).  tools/compare_golden.py replays
      the same substep through this repo's oracle stage by stage and names the FIRST stage and link that differ by
-     more than 1e-5 — so a mismatch says which of DESIGN.md §9's guesses is wrong.
+     more than 1e-5 — so a mismatch says which of DESIGN.md §9's guesses is wrong; `--search` replays it under every
+     combination of the specification switches (mbd_model_flags) and names the combination that fits;
+ (C) a ball with elasticity 0.5 dropped onto the floor (z, vz per substep): the restitution clamp's sign convention.
 
 Nothing here runs in the build container (jax/brax are absent) and no golden is ever fabricated.
 """
@@ -133,6 +135,37 @@ def dump_substep_stages(env, state_init, action, out, prefix=""):
     out.update({(k if k.startswith("sys_") else prefix + k): v for k, v in rec.items() if not (prefix and k.startswith("sys_"))})
 
 
+BOUNCE_XML = """<mujoco><compiler angle="degree" inertiafromgeom="true"/>
+<default><geom conaffinity="0" contype="0"/></default><option timestep="0.002"/>
+<custom><numeric name="elasticity" data="0.5"/></custom>
+<worldbody><geom conaffinity="1" type="plane" size="5 5 1"/>
+<body name="ball" pos="0 0 0.6"><joint type="free" name="root"/>
+<geom type="sphere" size="0.1" contype="1"/></body></worldbody></mujoco>"""
+
+
+def dump_bounce(out):
+    """(C) restitution: a ball with elasticity 0.5 dropped 0.5 m onto the floor through Brax's positional pipeline — the
+    only record with elasticity != 0 (every env of the reference has 0).  z(t) and vz(t) of 600 substeps: a rebound at
+    about half the impact speed means the velocity solve keeps max(-e vn, 0) (this repo's default since round 3); no
+    rebound means the literal min(..) of eq. 34 (MBD_FLAG_RESTITUTION_MIN).  tools/compare_golden.py reads the ratio.
+    Best effort: a Brax whose loader rejects the file leaves a note instead of a record."""
+    try:
+        import jax
+        from jax import numpy as jnp
+        from brax.io import mjcf
+        from brax.positional import pipeline
+        sys_ = mjcf.loads(BOUNCE_XML)
+        st = jax.jit(pipeline.init)(sys_, sys_.init_q, jnp.zeros(sys_.qd_size()))
+        step = jax.jit(pipeline.step)
+        zs, vz = [], []
+        for _ in range(600):
+            st = step(sys_, st, jnp.zeros(sys_.act_size()))
+            zs.append(float(st.x.pos[0, 2])); vz.append(float(st.xd.vel[0, 2]))
+        out["bounce_z"], out["bounce_vz"], out["bounce_elasticity"] = np.asarray(zs), np.asarray(vz), np.asarray(0.5)
+    except Exception as e:  # noqa: BLE001
+        print(f"NOTE: the restitution record was not produced on this Brax ({type(e).__name__}: {e})")
+
+
 def main():
     ref, env_name, N, H, steps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
     sys.path.insert(0, ref)
@@ -168,6 +201,7 @@ def main():
         for _ in range(12):
             st = step_env(st, jnp.full((Nu,), 0.3))
         dump_substep_stages(env, st, jnp.full((Nu,), 0.3), out, prefix="contact_")
+        dump_bounce(out)  # (C) the one record with elasticity != 0: settles the restitution clamp's sign convention
     Ybar = jnp.zeros([H, Nu])
     r = rng_exp
     for k, i in enumerate(range(Nd - 1, Nd - 1 - steps, -1)):
