@@ -362,8 +362,11 @@ int mbd_plan_enable_timing(mbd_plan* plan, int enable);
 /* ------------------------------------------------------------------------------------------------ */
 typedef struct mbd_sweep mbd_sweep;
 #define MBD_SWEEP_MAX_PLANS 32
-/* cfg: as for mbd_plan_create (update_method 0, unsharded; Nsample * 4 bytes <= 48 KB: larger plans fill the
- * chip on their own — run them as plans).  temps: [n_plans] temp_sample per plan, or NULL: cfg->temp_sample. */
+/* cfg: as for mbd_plan_create (unsharded; Nsample * 4 bytes <= 48 KB: larger plans fill the chip on their own — run
+ * them as plans).  update_method 0: MBD plans; 1 / 2 / 3: the path-integral baselines mppi / cma-es / cem
+ * (run_mbd.py:22-26,46-50 over path_integral.py:111-127; Ndiffuse plays Nrefine, no demos): one sampling launch, one rollout
+ * launch and the update rule's kernels over all plans per refinement step.  temps: [n_plans] temp_sample per plan, or
+ * NULL: cfg->temp_sample. */
 int mbd_sweep_create(mbd_env* env, const mbd_plan_config* cfg, int n_plans, const float* temps, mbd_sweep** out);
 int mbd_sweep_destroy(mbd_sweep* sweep);
 /* state_init of plan k (HOST, state_size floats) */
@@ -373,6 +376,8 @@ int mbd_sweep_set_state0(mbd_sweep* sweep, int k, const float* state0);
  * [n_plans][Ndiffuse-1], rew_final_out [n_plans]; loop_seconds_out: wall time of the lockstep loop.  Synchronous. */
 int mbd_sweep_run(mbd_sweep* sweep, const uint32_t* keys, float* mu_0ts_out, float* rew_means_out,
                   float* rew_final_out, double* loop_seconds_out);
+/* path-integral sweeps: the carried sampling sigma of every plan after the last run (path_integral.py:113,131); HOST [n_plans] */
+int mbd_sweep_get_sigmas(mbd_sweep* sweep, float* sigmas_out);
 /* average milliseconds of the sweep's rollout launches since the last reset (hipEvents on the launch stream) */
 int mbd_sweep_kernel_time(mbd_sweep* sweep, int enable, float* avg_ms_out, int* count_out);
 

@@ -42,7 +42,7 @@ EXPORTS = [
     "mbd_plan_schedule", "mbd_plan_set_state0", "mbd_plan_sample_rollout", "mbd_plan_prefetch_noise", "mbd_plan_score_update",
     "mbd_plan_set_sigma", "mbd_plan_get_sigma", "mbd_plan_reverse_once", "mbd_plan_run", "mbd_plan_eval", "mbd_plan_peek", "mbd_plan_kernel_time",
     "mbd_plan_enable_timing",
-    "mbd_sweep_create", "mbd_sweep_destroy", "mbd_sweep_set_state0", "mbd_sweep_run", "mbd_sweep_kernel_time",
+    "mbd_sweep_create", "mbd_sweep_destroy", "mbd_sweep_set_state0", "mbd_sweep_run", "mbd_sweep_kernel_time", "mbd_sweep_get_sigmas",
     "mbd_exchange_create", "mbd_exchange_destroy", "mbd_exchange_local_handle", "mbd_exchange_connect",
     "mbd_exchange_all_gather", "mbd_exchange_status", "mbd_exchange_fine_grained",
 ]
@@ -111,6 +111,7 @@ def load() -> C.CDLL:
     lib.mbd_sweep_set_state0.argtypes = [_vp, _i, _vp]
     lib.mbd_sweep_run.argtypes = [_vp, _vp, _vp, _vp, _vp, C.POINTER(C.c_double)]
     lib.mbd_sweep_kernel_time.argtypes = [_vp, _i, _fp, C.POINTER(_i)]
+    lib.mbd_sweep_get_sigmas.argtypes = [_vp, _vp]
     lib.mbd_exchange_create.argtypes = [_i, _i, _i, _i, _i, C.POINTER(_vp)]
     lib.mbd_exchange_destroy.argtypes = [_vp]
     lib.mbd_exchange_local_handle.argtypes = [_vp, _vp]

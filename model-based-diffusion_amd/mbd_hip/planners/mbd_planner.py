@@ -56,19 +56,22 @@ def apply_recommended(args: Args) -> None:
 
 
 class Sweep:
-    """Owner of an ``mbd_sweep`` handle: several MBD plans of one env (same sizes and schedule; seeds, start states and
+    """Owner of an ``mbd_sweep`` handle: several plans of one env (same sizes and schedule; seeds, start states and
     temperatures may differ) advanced in lockstep — ONE rollout launch over all their candidates and ONE score launch per
-    diffusion step (mbd/scripts/run_mbd.py:17-64).  Every plan's result is bit-identical to ``Plan.run`` on its own."""
+    diffusion step (mbd/scripts/run_mbd.py:17-64).  Every plan's result is bit-identical to ``Plan.run`` on its own.
+    ``update_method``: 0 MBD plans; 1 / 2 / 3 the path-integral baselines mppi / cma-es / cem (``args`` is then a
+    path_integral.Args: Nrefine plays Ndiffuse)."""
 
-    def __init__(self, env, args, n_plans: int, temps=None, literal_score: bool = True):
+    def __init__(self, env, args, n_plans: int, temps=None, literal_score: bool = True, update_method: int = 0):
         self.lib = _capi.load()
         self.env = env
         cfg = _capi.PlanConfig()
-        cfg.Nsample, cfg.Hsample, cfg.Ndiffuse = args.Nsample, args.Hsample, args.Ndiffuse
+        cfg.Nsample, cfg.Hsample = args.Nsample, args.Hsample
+        cfg.Ndiffuse = getattr(args, "Ndiffuse", None) or args.Nrefine  # path_integral.Args calls it Nrefine
         cfg.temp_sample = args.temp_sample
-        cfg.beta0, cfg.betaT = args.beta0, args.betaT
-        cfg.enable_demo = int(args.enable_demo)
-        cfg.update_method = 0
+        cfg.beta0, cfg.betaT = getattr(args, "beta0", 1e-4), getattr(args, "betaT", 1e-2)
+        cfg.enable_demo = int(getattr(args, "enable_demo", False))
+        cfg.update_method = int(update_method)
         cfg.prng_impl = prng_impl()
         cfg.shard_begin, cfg.shard_count = 0, args.Nsample
         cfg.literal_score = int(literal_score)
@@ -99,6 +102,12 @@ class Sweep:
         _capi.check(self.lib.mbd_sweep_run(self.h, _capi.np_ptr(k), _capi.np_ptr(mu), _capi.np_ptr(rm), _capi.np_ptr(rf),
                                            C.byref(secs)))
         return mu, rm, rf, secs.value
+
+    def get_sigmas(self):
+        """path-integral sweeps: every plan's carried sigma after the last run (path_integral.py:113,131)."""
+        out = np.zeros(self.P, np.float32)
+        _capi.check(self.lib.mbd_sweep_get_sigmas(self.h, _capi.np_ptr(out)))
+        return out
 
     def kernel_time(self, enable=True):
         ms, n = C.c_float(), C.c_int()

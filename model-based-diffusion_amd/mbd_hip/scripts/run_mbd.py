@@ -160,8 +160,8 @@ def run_replicated(plan_args, device: int | None = None, group=None):
 
 
 def _run_path_integral_seq(arg_list, device):
-    """The path-integral baselines (run_mbd.py:22-26,46-50) run one plan after another, each timed end to end like
-    the reference does (`time()` around the call, :21,34)."""
+    """The path-integral baselines (run_mbd.py:22-26,46-50) one plan after another, each timed end to end like the
+    reference does (`time()` around the call, :21,34) — what plans that do not batch fall back to."""
     from ..planners import path_integral
     rews, times = [], []
     for a in arg_list:
@@ -171,16 +171,59 @@ def _run_path_integral_seq(arg_list, device):
     return np.array(rews), np.array(times)
 
 
+def run_path_integral_sweep(arg_list, device: int = 0, return_details: bool = False):
+    """The path-integral plans of a sweep (a list of path_integral.Args: one env, one update_method, the same sizes; seeds
+    and temperatures may differ) as ONE mbd_sweep: per refinement step one sampling launch, one rollout launch over all
+    the plans' candidates and the update rule's kernels with one row per plan.  Bit-identical to running
+    path_integral.run_path_integral on each.  Returns (rew_final array, seconds of the lockstep loop[, details])."""
+    import contextlib
+    import io
+    from ..planners import path_integral
+    from ..planners.mbd_planner import Sweep
+    impl = prng_impl()
+    resolved = []
+    for a in arg_list:
+        a = replace(a)
+        if not a.disable_recommended_params:  # path_integral.py:86-92
+            a.temp_sample = path_integral.TEMP_RECOMMEND.get(a.env_name, a.temp_sample)
+            a.Nrefine = path_integral.NREFINE_RECOMMEND.get(a.env_name, a.Nrefine)
+            a.Nsample = path_integral.NSAMPLE_RECOMMEND.get(a.env_name, a.Nsample)
+            a.Hsample = path_integral.HSAMPLE_RECOMMEND.get(a.env_name, a.Hsample)
+        resolved.append(a)
+    a0 = resolved[0]
+    same = all((a.env_name, a.update_method, a.Nsample, a.Hsample, a.Nrefine) ==
+               (a0.env_name, a0.update_method, a0.Nsample, a0.Hsample, a0.Nrefine) for a in resolved)
+    if not same or len(resolved) > 32 or a0.Nsample * 4 > 48 * 1024 or a0.env_name in ("car2d", "pushT"):
+        rews, times = _run_path_integral_seq(arg_list, device)
+        return (rews, float(times.sum()), None) if return_details else (rews, float(times.sum()))
+    env = get_env(a0.env_name, device=device)
+    sweep = Sweep(env, a0, len(resolved), temps=[a.temp_sample for a in resolved],
+                  update_method=path_integral.UPDATE_METHODS[a0.update_method])
+    keys = []
+    for k, a in enumerate(resolved):
+        rng = _capi.prng_key(a.seed)  # path_integral.py:57
+        rng, rng_reset = _capi.prng_split(rng, 2, impl)  # :99
+        sweep.set_state0(k, env.reset(rng_reset))
+        rng_exp, _ = _capi.prng_split(rng, 2, impl)  # :144
+        keys.append(rng_exp)
+    mu, rew_means, rews, secs = sweep.run(np.array(keys, np.uint32))
+    sigmas = sweep.get_sigmas()
+    sweep.close()
+    if return_details:
+        return np.array(rews), secs, dict(mu_0ts=mu, rew_means=rew_means, sigma_final=sigmas)
+    return np.array(rews), secs
+
+
 def run_multiple_seed(args: Args, device: int | None = None, **plan_kw):
     """run_mbd.py:17-39: seeds 0..7, mean +- std of the final reward and the time."""
     if args.algo == "path_integral":  # :22-26
         from ..planners import path_integral
-        rews, times = _run_path_integral_seq(
-            [path_integral.Args(seed=seed, env_name=args.env_name, update_method=args.update_method, **plan_kw)
-             for seed in range(8)], device or 0)
+        plans = [path_integral.Args(seed=seed, env_name=args.env_name, update_method=args.update_method, **plan_kw)
+                 for seed in range(8)]
+        rews, secs = run_path_integral_sweep(plans, device or 0)  # (one sweep: one rollout launch per refinement step)
         print(f"rew: {rews.mean():.2f} \\pm {rews.std():.2f}")
-        print(f"time: {times.mean():.2f} \\pm {times.std():.2f}")
-        return rews, float(times.sum())
+        print(f"time: {secs / len(plans):.2f} per plan ({secs:.2f} s for the batch of {len(plans)})")
+        return rews, float(secs)
     if args.algo != "mbd":
         raise NotImplementedError  # :32-33
     plans = [mbd_planner.Args(seed=seed, env_name=args.env_name, not_render=True, **plan_kw) for seed in range(8)]
@@ -197,7 +240,7 @@ def run_multiple_temp(args: Args, device: int | None = None, **plan_kw):
     temps = np.array([0.01, 0.03, 0.06, 0.1, 0.2, 0.4, 0.6, 0.8])
     if args.algo == "path_integral":
         from ..planners import path_integral
-        rews, _ = _run_path_integral_seq(
+        rews, _ = run_path_integral_sweep(
             [path_integral.Args(seed=0, env_name=args.env_name, temp_sample=float(t), **plan_kw) for t in temps], device or 0)
     elif args.algo == "mbd":
         plans = [mbd_planner.Args(seed=0, env_name=args.env_name, temp_sample=float(t), not_render=True,

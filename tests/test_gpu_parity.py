@@ -1226,6 +1226,45 @@ def test_temperature_sweep_equals_the_plans_run_alone(gpu):
         assert np.array_equal(mu, det["mu_0ts"]) and np.float32(r) == np.float32(r_seq)
 
 
+@pytest.mark.parametrize("impl", [1, 0])
+@pytest.mark.parametrize("method", ["mppi", "cma-es", "cem"])
+@pytest.mark.parametrize("name,N,H,Nr", [("hopper", 256, 50, 10), ("humanoidrun", 128, 20, 8), ("ant", 33, 12, 6)])
+def test_path_integral_sweep_equals_the_plans_run_alone(gpu, method, name, N, H, Nr, impl, monkeypatch):
+    """Round-3 verdict item 7: the path-integral baselines' sweeps (mbd/scripts/run_mbd.py:22-26,46-50 over
+    path_integral.py:111-127) as ONE mbd_sweep — one sampling launch, one rollout launch and the update rule's kernels
+    over all plans per refinement step.  Five seeds with five temperatures: mu_0ts, per-step mean rewards, the carried
+    sigma (cma-es) and the final reward of every plan equal path_integral.run_path_integral on that plan alone, bit for
+    bit, in both threefry layouts."""
+    monkeypatch.setenv("MBD_THREEFRY_PARTITIONABLE", str(impl))
+    from mbd_hip.planners import path_integral
+    from mbd_hip.scripts.run_mbd import run_path_integral_sweep
+    temps = [0.05, 0.1, 0.2, 0.4, 0.8]
+    plans = [path_integral.Args(seed=s, env_name=name, update_method=method, Nsample=N, Hsample=H, Nrefine=Nr,
+                                temp_sample=temps[s], disable_recommended_params=True) for s in range(5)]
+    rews, secs, det = run_path_integral_sweep(plans, return_details=True)
+    assert det is not None and np.isfinite(det["mu_0ts"]).all()
+    for k, a in enumerate(plans):
+        r_seq, d = path_integral.run_path_integral(path_integral.Args(**vars(a)), return_details=True)
+        assert np.array_equal(det["mu_0ts"][k], d["mu_0ts"]), (method, name, k)
+        assert np.array_equal(det["rew_means"][k], d["rew_means"])
+        assert np.float32(det["sigma_final"][k]) == np.float32(d["sigma_final"])
+        assert np.float32(rews[k]) == np.float32(r_seq)
+    assert len({np.asarray(m).tobytes() for m in det["mu_0ts"]}) == len(plans)  # (five different plans)
+
+
+def test_run_multiple_seed_path_integral_is_one_sweep(gpu, capsys):
+    """mbd_hip.scripts.run_mbd.run_multiple_seed(algo="path_integral") (run_mbd.py:17-39): eight seeds through ONE
+    sweep, the rewards those of the eight plans run alone."""
+    from mbd_hip.planners import path_integral
+    from mbd_hip.scripts import run_mbd
+    kw = dict(Nsample=64, Hsample=20, Nrefine=6, disable_recommended_params=True)
+    rews, secs = run_mbd.run_multiple_seed(run_mbd.Args(algo="path_integral", update_method="cma-es", env_name="hopper"), **kw)
+    assert len(rews) == 8 and "per plan" in capsys.readouterr().out
+    for seed in (0, 7):
+        r = path_integral.run_path_integral(path_integral.Args(seed=seed, env_name="hopper", update_method="cma-es", **kw))
+        assert np.float32(r) == np.float32(rews[seed])
+
+
 def test_sweep_rejects_what_it_does_not_batch(gpu):
     from mbd_hip.envs import get_env
     from mbd_hip.planners.mbd_planner import Args, Sweep
