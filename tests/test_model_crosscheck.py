@@ -1,0 +1,145 @@
+"""Breaks the shared-compiler blind spot (round-3 verdict item 4): mbd_hip/mjcf.py compiles the models for the kernels AND
+for the checker, so its errors pass every bit-exact test.  oracle/model_reader.py is a second, deliberately dumb reader
+(world-frame facts straight from the XML, textbook solids + parallel axis, no shared code); here every compiled model
+(assets/compiled/*.json, the data the library embeds) is put through the checker's forward kinematics and compared with
+it: link tree, masses, centres of mass, inertia tensors (through the spring_inertia_scale exponent), joint anchors seen
+from both sides, hinge and slide axes, joint limits, actuator order / gears / control ranges, collider spheres."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_model
+from mbd_hip.envs import specs
+from oracle import model_reader
+from test_oracle_physics import _rot
+
+REF = os.environ.get("MBD_REFERENCE_PATH", "/root/reference")
+OWN = os.path.join(ROOT, "model-based-diffusion_amd", "assets")
+
+
+def _xml(name):
+    spec = specs.SPECS[name]
+    return os.path.join(REF, "mbd", "assets", spec["xml"]) if spec["from_reference"] else os.path.join(OWN, spec["xml"])
+
+
+def _R(q):
+    return np.array([_rot(q, e) for e in np.eye(3)]).T
+
+
+def test_closed_forms_against_monte_carlo():
+    """the reader's solids (sphere; capsule = cylinder + two hemispheres, 83/320 m r^2 transverse) against brute-force
+    integration of a skew capsule and a sphere: mass to 1 %, centre to 2 mm, tensor to 2 %"""
+    a, b, r = np.array([0.1, -0.2, 0.05]), np.array([0.35, 0.1, 0.4]), 0.07
+    for kind, bb in (("capsule", b), ("sphere", a)):
+        m, c, I = model_reader.combine(model_reader._solid(kind, a, bb, r, 900.0))
+        m2, c2, I2 = model_reader.monte_carlo(kind, a, bb, r, 900.0, n=3_000_000)
+        assert abs(m - m2) / m < 1e-2 and np.abs(c - c2).max() < 2e-3
+        assert np.abs(I - I2).max() / np.abs(I).max() < 2e-2
+
+
+@pytest.mark.parametrize("name", sorted(specs.SPECS))
+def test_compiled_model_matches_the_independent_reader(orc, name):
+    path = _xml(name)
+    if not os.path.exists(path):
+        pytest.skip(f"{path} is not on this box (the reference checkout lives in the build container only)")
+    rd = model_reader.read(path, drop_suffix=specs.SPECS[name].get("drop_suffix"))
+    _compare(orc, name, load_model(name), rd)
+
+
+def test_the_crosscheck_has_teeth(orc, tmp_path):
+    """Round 3's three real compile defects, re-planted one at a time in a model compiled by the product's compiler, must
+    each fail the comparison: halfcheetah without <compiler settotalmass> (it weighed 21.2 kg), ant's aux capsules moved
+    onto the hip links, and a collider sphere on the wrong end of a capsule."""
+    from mbd_hip import mjcf
+
+    def compiled(name, edit):
+        spec = specs.SPECS[name]
+        text = edit(open(_xml(name)).read())
+        f = tmp_path / f"{name}_planted.xml"
+        f.write_text(text)
+        return mjcf.load(str(f), env_name=name, n_frames=spec["n_frames"], reset_noise=spec["reset_noise"],
+                         reward_params=spec.get("reward_params", ()), gear_override=spec.get("gear_override", ()))
+
+    rd = model_reader.read(_xml("halfcheetah"))
+    _compare(orc, "halfcheetah", compiled("halfcheetah", lambda t: t), rd)            # (the plumbing itself passes)
+    with pytest.raises(AssertionError):
+        _compare(orc, "halfcheetah", compiled("halfcheetah", lambda t: t.replace(' settotalmass="14"', "")), rd)
+    m = compiled("hopper", lambda t: t)
+    m.fields["col_pos"] = np.array(m.fields["col_pos"], np.float32)
+    m.fields["col_pos"][0, 0] *= -1.0                                                   # the toe sphere on the heel side
+    with pytest.raises(AssertionError):
+        _compare(orc, "hopper", m, model_reader.read(_xml("hopper")))
+    m = compiled("ant", lambda t: t)
+    m.fields["com"] = np.array(m.fields["com"], np.float32)
+    m.fields["com"][1] += np.float32(0.01)                                              # a link's centre of mass 1 cm off
+    with pytest.raises(AssertionError):
+        _compare(orc, "ant", m, model_reader.read(_xml("ant")))
+
+
+def _compare(orc, name, m, rd):
+    spec = specs.SPECS[name]
+    F, L = m.fields, m.n_links
+    links = rd["links"]
+    assert [l["name"] for l in links] == m.link_names and [l["parent"] for l in links] == [int(p) for p in F["parent"][:L]]
+    ms = m.to_struct()
+    q0 = m.init_q.copy()
+    for k, off in enumerate(spec.get("init_q_offset", ())):   # (cartpole's reset offset is not the pose of the file)
+        q0[k] -= off
+    st = orc.forward(ms, q0, np.zeros(m.qd_size(), np.float32)).astype(np.float64)
+    sis = rd["custom"].get("spring_inertia_scale", 0.0)
+    sms = rd["custom"].get("spring_mass_scale", 0.0)
+    names = {}
+    for l, ln in enumerate(links):
+        p, Rl = st[l, 0:3], _R(st[l, 3:7])
+        # mass, centre of mass
+        assert abs(1.0 / float(F["inv_mass"][l]) - ln["mass"] ** (1.0 - sms)) / ln["mass"] < 2e-6, (name, ln["name"])
+        assert np.abs(p - ln["com"]).max() < 2e-6, (name, ln["name"], p, ln["com"])
+        # inertia: the model holds V diag(lam^-(1 - sis)) V^T in the link frame
+        ii = np.asarray(F["inv_inertia"][l], np.float64)
+        Wm = Rl @ np.array([[ii[0], ii[3], ii[4]], [ii[3], ii[1], ii[5]], [ii[4], ii[5], ii[2]]]) @ Rl.T
+        lam, V = np.linalg.eigh(ln["inertia"])
+        Wr = V @ np.diag(lam ** -(1.0 - sis)) @ V.T
+        assert np.abs(Wm - Wr).max() / np.abs(Wr).max() < 5e-6, (name, ln["name"])
+        # joints
+        hinges = [j for j in ln["joints"] if j["kind"] == "hinge"]
+        slides = [j for j in ln["joints"] if j["kind"] == "slide"]
+        free = [j for j in ln["joints"] if j["kind"] == "free"]
+        if free:
+            assert int(F["n_rot"][l]) == -1
+            continue
+        assert int(F["n_rot"][l]) == len(hinges) and int(F["n_slide"][l]) == len(slides)
+        anchor = (hinges or slides)[0]["anchor"]
+        par = int(F["parent"][l])
+        Pp, PR = (st[par, 0:3], _R(st[par, 3:7])) if par >= 0 else (np.zeros(3), np.eye(3))
+        assert np.abs(p + Rl @ np.asarray(F["ac_pos"][l], float) - anchor).max() < 2e-6, (name, ln["name"], "child anchor")
+        assert np.abs(Pp + PR @ np.asarray(F["ap_pos"][l], float) - anchor).max() < 2e-6, (name, ln["name"], "parent anchor")
+        Jc = Rl @ _R(np.asarray(F["ac_rot"][l], float))       # joint frame on the child, world
+        Jp = PR @ _R(np.asarray(F["ap_rot"][l], float))       # ... on the parent: the same frame at the file's pose
+        assert np.abs(Jc - Jp).max() < 2e-6
+        for k, j in enumerate(hinges):
+            sg = float(F["rot_sign"][l][k])
+            assert np.abs(Jc[:, k] * sg - j["axis"]).max() < 2e-6, (name, ln["name"], "hinge axis", k)
+            assert np.abs(Rl @ np.asarray(F["rot_axis"][l][k], float) - j["axis"]).max() < 2e-6
+            lim = j["limited"] == "true" or (j["limited"] not in ("true", "false") and j["has_range"])
+            lo, hi = (j["range"] if sg > 0 else -j["range"][::-1]) if (lim and j["has_range"]) else (-1e9, 1e9)
+            assert abs(float(F["rot_lo"][l][k]) - lo) < 1e-6 * max(1, abs(lo)) and abs(float(F["rot_hi"][l][k]) - hi) < 1e-6 * max(1, abs(hi))
+            names[j["name"]] = (l, k, sg)
+        for k, j in enumerate(slides):
+            assert np.abs(Jp @ np.asarray(F["slide_axis"][l][k], float) - j["axis"]).max() < 2e-6, (name, ln["name"], "slide axis", k)
+            names[j["name"]] = (l, 3 + k, 1.0)
+        # colliders: the link's spheres that can touch the floor, as a set
+        mine = sorted([tuple(np.round(p + Rl @ np.asarray(F["col_pos"][c], float), 5)) + (round(float(F["col_radius"][c]), 6),)
+                       for c in range(int(F["n_col"])) if int(F["col_link"][c]) == l])
+        theirs = sorted([tuple(np.round(e, 5)) + (round(r, 6),) for e, r in ln["colliders"]])
+        assert len(mine) == len(theirs) and np.allclose(np.array(mine), np.array(theirs), atol=2e-5) if mine else not theirs, (name, ln["name"], mine, theirs)
+    # actuators: file order, dof, gear (the spec's positional-backend override where there is one), control range
+    assert int(F["n_act"]) == len(rd["actuators"])
+    over = spec.get("gear_override", ())
+    for a, (jname, gear, rng) in enumerate(rd["actuators"]):
+        l, slot, sg = names[jname]
+        assert (int(F["act_link"][a]), int(F["act_slot"][a])) == (l, slot), (name, jname)
+        want = (over[a] if len(over) else gear)
+        assert abs(abs(float(F["act_gear"][a])) - abs(want)) < 1e-5 * abs(want) and np.sign(float(F["act_gear"][a])) == np.sign(gear) * sg
+        assert abs(float(F["act_lo"][a]) - rng[0]) < 1e-6 * max(1, abs(rng[0])) and abs(float(F["act_hi"][a]) - rng[1]) < 1e-6 * max(1, abs(rng[1]))
+    assert abs(sum(1.0 / float(x) for x in F["inv_mass"][:L]) - rd["total_mass"]) / rd["total_mass"] < 2e-6 or sms != 0.0
