@@ -2,7 +2,7 @@
 // (+1, -4, -6) and (+1, -2, -4, -6) of mbd_kernels.h).  Its own file because it is built with its own scheduler strategy
 // (-mllvm -amdgpu-sched-strategy=iterative-ilp, __graft_entry__.build): same-box A/B against the default strategy,
 // profiles/r03_hot3d_sched_ab.txt — humanoidrun N=1024 0.5499 -> 0.5427 ms (+1.3 %), N=4096 +1.7 %, humanoidtrack +0.8 %.
-// (The general instantiations stay in mbd_capi.hip with the default: one of them crashes this compiler's register
+// (The general instantiations stay in mbd_env.hip with the default: one of them crashes this compiler's register
 // allocator under the iterative strategy.)
 #define MBD_SHARED_ONLY 1
 #include "mbd_kernels.h"

@@ -1,5 +1,5 @@
 // mbd_launch.h — the one launch site of every rollout instantiation (host side; shared by the translation units that
-// hold rollout kernels: mbd_capi.hip and mbd_pk2.hip).
+// hold rollout kernels: mbd_env.hip, mbd_hot3d.hip, mbd_pk2.hip, mbd_planar.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>

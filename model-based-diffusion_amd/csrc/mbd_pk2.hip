@@ -2,7 +2,7 @@
 // with its own scheduler strategy (-mllvm -amdgpu-sched-strategy=iterative-ilp, __graft_entry__.build): a v_pk_*_f32
 // result cannot be read by the very next instruction (the compiler inserts an s_nop), and these kernels are almost
 // entirely dependent packed chains — the default strategy leaves 97 such wait states per substep, the iterative one 27.
-// The one-candidate-per-lane kernels (mbd_capi.hip) measured slower under that strategy and keep the default.
+// The one-candidate-per-lane kernels (mbd_env.hip) measured slower under that strategy and keep the default.
 #define MBD_SHARED_ONLY 1
 #include "mbd_pk2.h"
 #include "mbd_launch.h"

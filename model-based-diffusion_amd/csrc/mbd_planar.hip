@@ -2,7 +2,7 @@
 // scheduler strategy (-mllvm -amdgpu-sched-strategy=max-ilp, __graft_entry__.build): the planar substeps are short
 // dependent chains around a few packed instructions, and the default strategy leaves 11-12 hazard s_nop per substep
 // where max-ilp leaves 4-5 (hopper 342 -> 336 instructions per substep, halfcheetah 398 -> 391, walker2d 371 -> 363:
-// a lone wavefront's time is its instruction count).  The 3-D kernels (mbd_capi.hip) keep the default.
+// a lone wavefront's time is its instruction count).  The 3-D kernels (mbd_env.hip) keep the default.
 #define MBD_SHARED_ONLY 1
 #include "mbd_planar.h"
 #include "mbd_launch.h"

@@ -140,7 +140,7 @@ def test_product_does_not_import_the_oracle():
 
 
 def test_dpp_lane_layouts_of_the_builtin_models(lib):
-    """Host logic of the DPP exchange (csrc/mbd_capi.hip::find_dpp_layout): every built-in tree gets a layout in
+    """Host logic of the DPP exchange (csrc/mbd_env.hip::find_dpp_layout): every built-in tree gets a layout in
     which each link sits on its own lane of the LPS-lane group and every s-th child (in link order) sits exactly
     shift[s] lanes below its parent — what the kernels' row shifts assume."""
     lib.mbd_debug_dpp_layout.restype = C.c_int

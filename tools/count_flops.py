@@ -14,7 +14,7 @@ import sys
 import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-# env -> template arguments of the instantiation launch_rollout() picks for it (csrc/mbd_capi.hip)
+# env -> template arguments of the instantiation launch_rollout() picks for it (csrc/mbd_env.hip)
 INSTANCES = {
     "humanoidrun": "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,0,7",
     "humanoidtrack": "16,true,false,3,1,1,-4,-6,0,false,true,3,false,false,3,5",

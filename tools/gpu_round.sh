@@ -19,7 +19,7 @@ if [[ " $what " == *" prof "* ]]; then
   cd /tmp && export TMPDIR=/tmp
   for c in metric hopper512 halfcheetah1024 humanoidrun4096 humanoidtrack2048demo humanoidrun8192 sweep8; do
     [[ " $what " == *" $c "* ]] || continue
-    B="python $R/bench.py --config $c --no-cpu-baseline --no-final-reward"
+    B="python $R/bench.py --config $c --no-cpu-baseline --no-final-reward --no-extras --repeats 2"
     rocprofv3 --kernel-trace --stats -d $OUT/prof_${c}_stats -o ${TAG} -- $B --steps 60 --warmup 10 > $OUT/prof_${c}_stats.log 2>&1
     rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY --kernel-trace -d $OUT/prof_${c}_sq -o ${TAG} -- $B --steps 20 --warmup 2 > $OUT/prof_${c}_sq.log 2>&1
     rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/prof_${c}_fetch -o ${TAG} -- $B --steps 20 --warmup 2 > $OUT/prof_${c}_fetch.log 2>&1

@@ -31,7 +31,7 @@ def main():
     rows = list(con.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
     lines = [f"# rocprofv3 --kernel-trace --stats ({tag})", "",
              f"command: `rocprofv3 --kernel-trace --stats -- python bench.py --config {config} --steps 60 --warmup 10 "
-             "--no-cpu-baseline --no-final-reward` (durations in microseconds)", "",
+             "--no-cpu-baseline --no-final-reward --no-extras --repeats 2` (durations in microseconds)", "",
              "| kernel | calls | total_us | avg_us | % |", "|---|---:|---:|---:|---:|"]
     for name, calls, tot, avg, pct in rows:
         lines.append(f"| `{name[:110]}` | {calls} | {tot:.1f} | {avg:.2f} | {pct:.2f} |")
