@@ -22,6 +22,7 @@
 
 #include "../../include/mbd_hip.h"
 #include "mbd_kernels.h"
+#include "mbd_step_kernels.h"
 
 using namespace mbd;
 
