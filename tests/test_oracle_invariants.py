@@ -238,3 +238,61 @@ def test_reauthored_models_have_the_stock_geoms_masses():
     aux, low = _capsule(.08, .2 * s2, 5.0), _capsule(.08, .4 * s2, 5.0)
     torso = 5.0 * 4.0 / 3.0 * math.pi * .25 ** 3 + 4 * aux
     assert np.allclose(mass("ant"), [torso] + [aux, low] * 4, rtol=2e-6)
+
+
+# ---- a sphere on an incline: rolling without slipping, and the transition to sliding ------------------------------------
+ROLLER = """<mujoco><compiler angle="degree" inertiafromgeom="true"/>
+<default><geom conaffinity="0" contype="0"/></default><option timestep="0.002" gravity="{gx} 0 {gz}"/>
+<custom><numeric name="spring_inertia_scale" data="0"/></custom>
+<worldbody><geom conaffinity="1" type="plane" size="5 5 1" friction="{mu} 0.005 0.0001"/>
+<body name="ball" pos="0 0 0.1"><joint type="free" name="root"/>
+<geom type="sphere" size="0.1" contype="1" friction="{mu} 0.005 0.0001"/></body></worldbody></mujoco>"""
+
+
+def _roll_down(orc, mu, deg, flags=0):
+    """(linear acceleration / (g sin theta), r * angular acceleration / linear acceleration) of a solid sphere released
+    on an incline of `deg` degrees (gravity tilted), second half of 0.6 s"""
+    th, g, dt, r = math.radians(deg), 9.81, 0.002, 0.1
+    m = _compile(ROLLER.format(gx=g * math.sin(th), gz=-g * math.cos(th), mu=mu)).with_spec(flags)
+    ms = m.to_struct()
+    st = orc.forward(ms, m.init_q, np.zeros(6, np.float32))
+    vs = []
+    for _ in range(300):
+        st = orc.substep(ms, st, np.zeros(0, np.float32))
+        vs.append((float(st[0, 7]), float(st[0, 11])))
+    vs = np.array(vs)
+    a = (vs[-1, 0] - vs[150, 0]) / (149 * dt)
+    al = (vs[-1, 1] - vs[150, 1]) / (149 * dt)
+    return a / (g * math.sin(th)), r * al / a
+
+
+@pytest.mark.parametrize("mu,deg", [(1.0, 5), (1.0, 15), (1.0, 30), (0.05, 5), (0.05, 15), (0.05, 30)])
+def test_sphere_on_an_incline_rolls_then_slides(orc, mu, deg):
+    """Contact, friction and rotational inertia together, against rigid-body mechanics that owe nothing to Brax (round 4):
+    a solid sphere rolls WITHOUT slipping while tan(theta) <= 3.5 mu — a = (5/7) g sin(theta), r alpha = a — and above that
+    SLIDES with Coulomb friction — a = g (sin - mu cos), r alpha = 2.5 mu g cos — spinning up more slowly than it
+    translates.  Stage (4)'s positional static friction carries the first regime, stage (6)'s bounded impulse the second:
+    the default friction bound (mu lambda_n / h as an IMPULSE) is the one that reproduces Coulomb's law."""
+    th = math.radians(deg)
+    a, ra = _roll_down(orc, mu, deg)
+    if math.tan(th) <= 3.5 * mu:
+        assert abs(a - 5.0 / 7.0) < 0.01 and abs(ra - 1.0) < 0.01, (a, ra)
+    else:
+        want_a = 1.0 - mu / math.tan(th)
+        want_ra = 2.5 * mu * math.cos(th) / (math.sin(th) - mu * math.cos(th))
+        assert abs(a - want_a) < 0.01 and abs(ra - want_ra) < 0.01, (a, ra, want_a, want_ra)
+
+
+def test_friction_velocity_bound_is_not_coulomb(orc):
+    """The alternative bound (MBD_FLAG_FRICTION_VEL_BOUND: mu lambda_n / h as a VELOCITY, eq. 30 of the paper taken
+    literally) is Coulomb friction with mu / w_t in place of mu — w_t = 1/m + r^2/I = 3.5 / m for a solid sphere — i.e. a
+    friction coefficient that depends on the body's mass (4.19 kg here: mu_eff = 1.2 mu; the 60 kg sled of
+    tests/test_spec_switches.py: far more).  Recorded here because it is the physical argument for the default; which
+    one Brax evaluates is still unpinned."""
+    th = math.radians(30)
+    a0, ra0 = _roll_down(orc, 0.05, 30)
+    a1, ra1 = _roll_down(orc, 0.05, 30, flags=16)
+    mass = 1000.0 * 4.0 / 3.0 * math.pi * 0.1 ** 3
+    mu_eff = 0.05 / (3.5 / mass)
+    assert abs(a0 - (1.0 - 0.05 / math.tan(th))) < 0.01
+    assert abs(a1 - (1.0 - mu_eff / math.tan(th))) < 0.01 and abs(a1 - a0) > 0.015, (a0, a1, mu_eff)
