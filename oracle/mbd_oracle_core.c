@@ -18,6 +18,10 @@
  *   - threefry2x32: pinned by the three Random123 known-answer vectors (tests/test_oracle_prng.py).
  *   - schedule: pinned by the f32 known answers of SURVEY.md §8(a) row A0.
  *   - car2d: pinned by closed-form cases (tests/test_oracle_car2d.py).
+ *   - score update, demo blend, softmax, weighted mean, the loop's key chain, car2d, the path-integral update rules: since
+ *     round 4 also pinned by the reference's OWN source executed under a numpy stand-in for jax (tools/make_ref_golden.py,
+ *     tests/golden/ref_*.npz, tests/test_ref_golden.py: BASELINE config 1 at all 49 steps) — at float32 round-off, since
+ *     numpy is not XLA.
  *   - split / random_bits layouts, uniform bit trick, normal, ErfInv coefficients: restated from the
  *     JAX/XLA sources and pinned by outputs of the real JAX printed in its public documentation (key
  *     splits and normal/uniform draws for PRNGKey(0)/PRNGKey(42) in the legacy layout and key(42) in the

@@ -640,26 +640,11 @@ static void link_origin_vel(const mbd_model_t* m, int l, const xf_t* x, const mo
   sp_sub3(xd[l].v, u, o);
 }
 
-/* env.step for one environment: n_frames substeps with the action held, then the reward
- * (PipelineEnv.pipeline_step + the env wrapper's _get_reward). returns the reward. */
-static real env_step(const mbd_model_t* m, xf_t* x, mo_t* xd, const float* action) {
-  const int L = m->n_links;
-  real tau_rot[MBD_MAX_LINKS * 3], tau_slide[MBD_MAX_LINKS * 3];
-  memset(tau_rot, 0, sizeof(tau_rot)); memset(tau_slide, 0, sizeof(tau_slide));
-  /* actuator.to_tau: clip to ctrlrange, times gear, scatter */
-  for (int a = 0; a < m->n_act; ++a) {
-    real u = sp_clip(R(action[a]), R(m->act_lo[a]), R(m->act_hi[a])) * R(m->act_gear[a]);
-    int l = m->act_link[a], s = m->act_slot[a];
-    if (s < 3) tau_rot[l * 3 + s] += u; else tau_slide[l * 3 + s - 3] += u;
-  }
-  real o0[3], v0[3];
-  const int planar = (m->flags & MBD_FLAG_PLANAR) != 0;
-  if (planar) { pl_origin3(m, 0, x, o0); v0[0] = v0[1] = v0[2] = R(0); }
-  else { link_origin(m, 0, x, o0); link_origin_vel(m, 0, x, xd, v0); }
-  for (int f = 0; f < m->n_frames; ++f) substep(m, x, xd, tau_rot, tau_slide);
-  real o1[3];
-  if (planar) pl_origin3(m, 0, x, o1); else link_origin(m, 0, x, o1);
-  (void)L;
+/* the env wrappers' _get_reward as functions of the root link's frame origin before (o0, with its velocity v0) and after
+ * (o1) the control step — every reward kind but cartpole's, which reads joint coordinates (env_step).  Exported as
+ * orc_reward so that tests can hold these expressions to the reference's own _get_reward code, executed
+ * (tools/make_ref_golden.py, tests/test_ref_golden.py). */
+static real reward_origin(const mbd_model_t* m, const real o0[3], const real v0[3], const real o1[3], const float* action) {
   switch (m->reward_kind) {
     case MBD_REW_HUMANOIDRUN: /* humanoidrun.py:46-51 */
       return o1[0] * R(1) - sp_clip(sp_abs(o1[2] - R(1.3)), R(-1), R(1)) * R(1) - sp_abs(o1[1]) * R(0.1);
@@ -682,6 +667,33 @@ static real env_step(const mbd_model_t* m, xf_t* x, mo_t* xd, const float* actio
                          ? R(m->reward_params[4]) : R(0);
       return (R(m->reward_params[0]) * ((o1[0] - o0[0]) / dtc) + healthy) - R(m->reward_params[1]) * ctrl;
     }
+    case MBD_REW_HUMANOIDSTANDUP: /* humanoidstandup.py:50-56 */
+      return R(1.5) - sp_clip(sp_abs(o1[2] - R(1.3)), R(-2), R(1)) - sp_abs(o1[0]) * R(0.1) - sp_abs(o1[1]) * R(0.1);
+    default: return 0;
+  }
+}
+
+/* env.step for one environment: n_frames substeps with the action held, then the reward
+ * (PipelineEnv.pipeline_step + the env wrapper's _get_reward). returns the reward. */
+static real env_step(const mbd_model_t* m, xf_t* x, mo_t* xd, const float* action) {
+  const int L = m->n_links;
+  real tau_rot[MBD_MAX_LINKS * 3], tau_slide[MBD_MAX_LINKS * 3];
+  memset(tau_rot, 0, sizeof(tau_rot)); memset(tau_slide, 0, sizeof(tau_slide));
+  /* actuator.to_tau: clip to ctrlrange, times gear, scatter */
+  for (int a = 0; a < m->n_act; ++a) {
+    real u = sp_clip(R(action[a]), R(m->act_lo[a]), R(m->act_hi[a])) * R(m->act_gear[a]);
+    int l = m->act_link[a], s = m->act_slot[a];
+    if (s < 3) tau_rot[l * 3 + s] += u; else tau_slide[l * 3 + s - 3] += u;
+  }
+  real o0[3], v0[3];
+  const int planar = (m->flags & MBD_FLAG_PLANAR) != 0;
+  if (planar) { pl_origin3(m, 0, x, o0); v0[0] = v0[1] = v0[2] = R(0); }
+  else { link_origin(m, 0, x, o0); link_origin_vel(m, 0, x, xd, v0); }
+  for (int f = 0; f < m->n_frames; ++f) substep(m, x, xd, tau_rot, tau_slide);
+  real o1[3];
+  if (planar) pl_origin3(m, 0, x, o1); else link_origin(m, 0, x, o1);
+  (void)L;
+  switch (m->reward_kind) {
     case MBD_REW_CARTPOLE: { /* cartpole.py:45: cos(q[1]) - |qd[0]|: hinge angle of link 1, slide velocity of link 0 */
       if (planar) {
         plink_t K[MBD_MAX_LINKS];
@@ -705,10 +717,13 @@ static real env_step(const mbd_model_t* m, xf_t* x, mo_t* xd, const float* actio
       sp_sincos(f1.ang[0], &sn, &cs);
       return cs - sp_abs(sp_dot3(vc, sx));
     }
-    case MBD_REW_HUMANOIDSTANDUP: /* humanoidstandup.py:50-56 */
-      return R(1.5) - sp_clip(sp_abs(o1[2] - R(1.3)), R(-2), R(1)) - sp_abs(o1[0]) * R(0.1) - sp_abs(o1[1]) * R(0.1);
-    default: return 0;
+    default: return reward_origin(m, o0, v0, o1, action);
   }
+}
+
+ORC_API float orc_reward(const mbd_model_t* m, const float* o0, const float* v0, const float* o1, const float* action) {
+  real a[3] = {R(o0[0]), R(o0[1]), R(o0[2])}, b[3] = {R(v0[0]), R(v0[1]), R(v0[2])}, c[3] = {R(o1[0]), R(o1[1]), R(o1[2])};
+  return (float)reward_origin(m, a, b, c, action);
 }
 
 ORC_API float orc_env_step(const mbd_model_t* m, const float* state_in, const float* action,

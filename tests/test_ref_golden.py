@@ -1,0 +1,203 @@
+"""Golden vectors produced by EXECUTING the reference's own source (tools/make_ref_golden.py): the reference's
+`mbd/planners/mbd_planner.py` (run_diffusion, reverse_once: :38-182), `mbd/utils.py` (rollout_us) and `mbd/envs/car2d.py`,
+loaded unchanged from /root/reference and run under a numpy stand-in for jax / flax.  They are not outputs of JAX (numpy's
+sin / cos / exp and pairwise sums stand where XLA has its own; the PRNG is this repo's pinned threefry restatement), so the
+bar here is float32 round-off — stated per quantity below — not bit equality.  What they DO pin, for the first time with
+code of the reference actually running: the planner algebra of every row A0, A4-A9 of SURVEY §8 (schedule, standardise with
+its zero-spread guard, the demo blend with its double temperature, softmax, weighted mean, the literal score update, the key
+chain of the loop), `rollout_us`, and the car2d env (RK4 step, action clip, collision rule, reward, demo log-density,
+rew_xref).  BASELINE config 1 (car2d N=128 H=30 Ndiffuse=50) is one of the files, teacher-forced at all 49 steps."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+GOLD = os.path.join(ROOT, "tests", "golden")
+XREF = os.path.join(ROOT, "model-based-diffusion_amd", "assets", "compiled", "car2d_xref.npy")
+FILES = ["config1", "demo", "demo256"]
+
+
+def _env(orc, g):
+    from oracle import planner as op
+    return op.OracleEnv(orc, "car2d", xref=np.load(XREF), rew_xref=float(g["rew_xref"]))
+
+
+def test_car2d_env_matches_the_executed_reference(orc):
+    """mbd/utils.py::rollout_us over mbd/envs/car2d.py::Car2d.step from 96 start poses (16 around the goal, many next to
+    obstacles) under random actions beyond the clip range: states to 2e-6, rewards to 2e-6, the collision rule's
+    outcome (blocked or moved) identical at every one of the 4800 steps, eval_xref_logpd to 1e-6."""
+    g = np.load(os.path.join(GOLD, "ref_car2d_env.npz"))
+    xref = np.load(XREF)
+    worst_q = worst_r = 0.0
+    for b in range(len(g["q0"])):
+        rew, qs = orc.car2d_rollout(g["q0"][b], g["us"][b][None], want_qs=True)
+        rew, qs = rew[0], qs[0]
+        moved_ref = np.abs(np.diff(np.concatenate([g["q0"][b][None], g["qs"][b]]), axis=0)).sum(1) > 0
+        moved = np.abs(np.diff(np.concatenate([g["q0"][b][None], qs]), axis=0)).sum(1) > 0
+        assert np.array_equal(moved, moved_ref), f"rollout {b}: a collision decided differently"
+        worst_q = max(worst_q, float(np.abs(qs - g["qs"][b]).max()))
+        worst_r = max(worst_r, float(np.abs(rew - g["rewss"][b]).max()))
+        assert abs(float(orc.car2d_xref_logpd(qs, xref)) - float(g["logpd"][b])) < 1e-6
+    assert worst_q < 2e-6 and worst_r < 2e-6, (worst_q, worst_r)
+    assert (g["rewss"] > 0).sum() > 100 and (g["rewss"] == 0).sum() > 1000   # (both regimes occur in the file)
+
+
+@pytest.mark.parametrize("name", FILES)
+def test_reverse_once_matches_the_executed_reference(orc, name):
+    """Every recorded call of the reference's reverse_once, teacher-forced (its rng and Ybar_i in): the key chain comes out
+    bit for bit; the candidates' rewards to 2e-6; logp0 / softmax weights to 1e-4 relative (a std over N in another
+    summation order, then exp); Ybar_{i-1} to 1e-5 (the north star's tolerance; 4e-6 observed where one weight is 0.998); the step's mean reward to 1e-6.  The schedule's sigmas enter through
+    Ybar (the reference's linspace runs in float64 under numpy, jax's in float32: one ulp of beta)."""
+    from oracle import planner as op
+    g = np.load(os.path.join(GOLD, f"ref_car2d_{name}.npz"))
+    N, H, Nd, temp, demo = int(g["N"]), int(g["H"]), int(g["Nd"]), float(g["temp"]), bool(g["demo"])
+    env = _env(orc, g)
+    st0 = env.reset(None, 1)
+    assert np.array_equal(st0, g["state_init"])
+    sched = orc.schedule(1e-4, 1e-2, Nd)
+    assert len(g["i"]) == Nd - 1 and list(g["i"]) == list(range(Nd - 1, 0, -1))
+    for k in range(len(g["i"])):
+        r2, Y, rm, det = op.reverse_once(orc, env, st0, int(g["i"][k]), g["rng_in"][k], g["Ybar_i"][k], sched, N, H, temp, 1,
+                                         enable_demo=demo)
+        assert np.array_equal(r2, g["rng_out"][k])
+        if k + 1 < len(g["i"]):
+            assert np.array_equal(g["rng_in"][k + 1], g["rng_out"][k])        # (the loop carries the key)
+            assert np.array_equal(g["Ybar_i"][k + 1], g["Ybar_im1"][k])
+        if k < len(g["eps"]):   # the layout of normal(key, (N, H, Nu)) as the reference consumes it
+            eps = orc.normal(orc.split(g["rng_in"][k], 2, 1)[1], (N, H, 2), 1)
+            assert np.array_equal(eps, g["eps"][k])
+        assert np.abs(det["rewss"] - g["rewss"][k]).max() < 2e-6
+        assert np.allclose(det["weights"], g["weights"][k], rtol=1e-4, atol=1e-9), k
+        assert abs(float(det["weights"].sum()) - 1.0) < 1e-5
+        assert np.abs(Y - g["Ybar_im1"][k]).max() < 1e-5, k
+        assert abs(float(rm) - float(g["rew_mean"][k])) < 1e-6
+    if demo:  # the blend did something: the weights are far from uniform at first and flatten as sigma shrinks
+        assert g["weights"][0].max() > 0.5 and g["weights"][-1].max() < 0.2
+    else:     # config 1: no candidate reaches the goal, the zero-spread guard makes the weights exactly uniform
+        assert np.all(g["weights"] == np.float32(1.0 / N))
+
+
+def test_rew_xref_and_final_reward(orc):
+    """env.rew_xref (car2d.py:71: vmap(get_reward)(xref).mean()) as the executed reference has it, against the checker's and
+    the library's host computation (same 50 x 2 demo file); the reference's rew_final of config 1 is 0 (no plan reaches
+    the goal without the demo at these sizes) and so is the checker's for the golden's final plan."""
+    g = np.load(os.path.join(GOLD, "ref_car2d_config1.npz"))
+    xref = np.load(XREF)
+    mine = np.mean([orc.car2d_reward(np.array([x[0], x[1], 0.0], np.float32)) for x in xref.astype(np.float32)])
+    assert abs(float(mine) - float(g["rew_xref"])) < 1e-6
+    env = _env(orc, g)
+    rew = env.rollout(env.reset(None, 1), g["Ybar_im1"][-1][None])
+    assert abs(float(np.mean(rew)) - float(g["rew_final"])) < 1e-6
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", FILES)
+def test_gpu_reverse_once_matches_the_executed_reference(name):
+    """The PRODUCT (libmbd_hip.so through the C ABI) against the same files, teacher-forced at every recorded step: key chain
+    exact, Ybar_{i-1} to 1e-5 (the north star's tolerance; 4e-6 observed where one weight is 0.998), the step's mean reward to 1e-6 — the HIP path held to vectors the reference's own code
+    produced, not only to this repo's checker."""
+    import ctypes as C
+    import torch
+    from mbd_hip import _capi
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.mbd_planner import Args, Plan
+    if _capi.device_count() < 1:
+        pytest.fail("GPU tests need a visible MI355X; the product has no CPU fallback")
+    g = np.load(os.path.join(GOLD, f"ref_car2d_{name}.npz"))
+    N, H, Nd, temp, demo = int(g["N"]), int(g["H"]), int(g["Nd"]), float(g["temp"]), bool(g["demo"])
+    env = get_env("car2d")
+    assert abs(env.rew_xref - float(g["rew_xref"])) < 1e-6
+    plan = Plan(env, Args(env_name="car2d", Nsample=N, Hsample=H, Ndiffuse=Nd, temp_sample=temp, enable_demo=demo,
+                          disable_recommended_params=True, not_render=True))
+    st = env.reset(_capi.prng_key(0))
+    assert np.array_equal(np.asarray(st.pipeline_state, np.float32).reshape(-1), g["state_init"])
+    plan.set_state0(st)
+    d_rm = torch.zeros(1, device="cuda")
+    for k in range(len(g["i"])):
+        d_Y = torch.tensor(g["Ybar_i"][k].reshape(-1), device="cuda")
+        key = (C.c_uint32 * 2)(int(g["rng_in"][k][0]), int(g["rng_in"][k][1]))
+        _capi.check(plan.lib.mbd_plan_reverse_once(plan.h, int(g["i"][k]), key, d_Y.data_ptr(), d_rm.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert [key[0], key[1]] == [int(x) for x in g["rng_out"][k]]
+        assert np.abs(d_Y.cpu().numpy().reshape(H, 2) - g["Ybar_im1"][k]).max() < 1e-5, k
+        assert abs(float(d_rm.item()) - float(g["rew_mean"][k])) < 1e-6
+        _, rewss, w = plan.peek()
+        assert np.abs(rewss - g["rewss"][k]).max() < 2e-6 and np.allclose(w, g["weights"][k], rtol=1e-4, atol=1e-9)
+    plan.close()
+
+
+@pytest.mark.gpu
+def test_gpu_car2d_env_matches_the_executed_reference():
+    """mbd_env_rollout of the library from the file's 96 start poses against the reference's rollout_us over Car2d.step."""
+    from mbd_hip import _capi
+    from mbd_hip.envs import get_env
+    if _capi.device_count() < 1:
+        pytest.fail("GPU tests need a visible MI355X; the product has no CPU fallback")
+    g = np.load(os.path.join(GOLD, "ref_car2d_env.npz"))
+    env = get_env("car2d")
+    st = env.reset(_capi.prng_key(0))
+    for b in range(0, len(g["q0"]), 3):
+        s = st.replace(pipeline_state=g["q0"][b].copy())
+        rew, qs = env.rollout(s, g["us"][b][None], want_xpos=True)
+        assert np.abs(rew.cpu().numpy()[0] - g["rewss"][b]).max() < 2e-6
+        assert np.abs(qs.cpu().numpy()[0] - g["qs"][b]).max() < 2e-6
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_path_integral_update_rules_match_the_executed_reference(orc, case):
+    """mbd/planners/path_integral.py:33-52 — softmax_update, cma_es_update, cem_update — executed on stored inputs: the
+    checker's update rules (what the MPPI / CMA-ES / CEM plans and sweeps of the library are held to bit for bit) give the
+    reference's new mean to 2e-6 and its sigma to 1e-6 relative; CEM picks the same ten candidates."""
+    g = np.load(os.path.join(GOLD, "ref_pi_updates.npz"))
+    rews, Y0s, mu, sigma, temp = g[f"rews{case}"], g[f"Y0s{case}"], g[f"mu{case}"], float(g[f"sigma{case}"]), float(g[f"temp{case}"])
+    for method, mname in ((1, "mppi"), (2, "cmaes"), (3, "cem")):
+        m2, s2, w, _ = orc.pi_update(method, rews, Y0s, mu, sigma, temp)
+        assert np.array_equal(w, g[f"weights{case}"])          # (the inputs the reference's functions were given)
+        assert np.abs(m2 - g[f"{mname}_mu{case}"]).max() < 2e-6, mname
+        assert abs(s2 - float(g[f"{mname}_sigma{case}"])) <= 1e-6 * abs(float(g[f"{mname}_sigma{case}"])), mname
+    assert float(g[f"cmaes_sigma{case}"]) != sigma and float(g[f"mppi_sigma{case}"]) == np.float32(sigma)
+
+
+def test_env_wrapper_rewards_match_the_executed_reference(orc):
+    """The Brax-backed wrappers' own `_get_reward` (humanoidrun.py:46-51, hopper.py:57-65, walker2d.py:57-62,
+    humanoidstandup.py:50-56, humanoidtrack.py:87-96 — lagged: from the INCOMING state), executed on 64 synthetic root
+    poses / velocities incl. the clips' kinks, against the checker's reward expressions (orc_reward: the same function
+    env_step uses; the kernels are held to it bit for bit): 1e-6."""
+    import ctypes as C
+    from conftest import load_model
+    g = np.load(os.path.join(GOLD, "ref_env_rewards.npz"))
+    f32 = np.ctypeslib.ndpointer(np.float32, flags="C_CONTIGUOUS")
+    orc.lib.orc_reward.restype = C.c_float
+    orc.lib.orc_reward.argtypes = [C.c_void_p, f32, f32, f32, f32]
+    pos, vel = g["root_pos"], g["root_vel"]
+    zero = np.zeros(3, np.float32)
+    for name in ("humanoidrun", "hopper", "walker2d", "humanoidstandup", "humanoidtrack"):
+        m = load_model(name)
+        ms = m.to_struct()
+        act = np.zeros(m.act_size(), np.float32)
+        for k in range(len(pos)):
+            if name == "humanoidtrack":   # (the reward of a step is computed from the state the step STARTED from)
+                mine = orc.lib.orc_reward(C.addressof(ms), pos[k].copy(), vel[k].copy(), zero, act)
+            else:
+                mine = orc.lib.orc_reward(C.addressof(ms), zero, zero, pos[k].copy(), act)
+            assert abs(mine - float(g[f"{name}_reward"][k])) < 1e-6, (name, k)
+
+
+def test_humanoidtrack_demo_matches_the_executed_reference(orc):
+    """humanoidtrack.py:17-44 executed (the demo pickle read by the reference's own constructor): the tracked links' indices,
+    the demo xref [5][50][3] (46 recorded rows padded by repeating the last, :38-39) and rew_xref = 1.0 equal what the
+    library embeds, exactly; eval_xref_logpd (:98-106) of 24 synthetic position tracks around the demo — inside and beyond
+    the 0.5 m clip — agrees with the checker's (which the logpd kernel is held to bit for bit) to 1e-6."""
+    from conftest import load_model
+    g = np.load(os.path.join(GOLD, "ref_env_rewards.npz"))
+    mine = np.load(os.path.join(ROOT, "model-based-diffusion_amd", "assets", "compiled", "jog_xref.npy"))
+    assert mine.shape == (5, 50, 3) and np.array_equal(mine, g["humanoidtrack_xref"])
+    assert np.array_equal(mine[:, 46:], np.repeat(mine[:, 45:46], 4, axis=1)) and float(g["humanoidtrack_rew_xref"]) == 1.0
+    m = load_model("humanoidtrack")
+    assert list(np.asarray(m.fields["track_link"], int)) == [int(x) for x in g["humanoidtrack_track_idx"]]
+    for b in range(len(g["humanoidtrack_xpos"])):
+        lp = orc.track_xref_logpd(g["humanoidtrack_xpos"][b], mine)
+        assert abs(float(lp) - float(g["humanoidtrack_logpd"][b])) < 1e-6, b
+    assert g["humanoidtrack_logpd"].min() < -0.9 and g["humanoidtrack_logpd"].max() > -0.05   # (both ends of the clip)
