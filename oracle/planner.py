@@ -16,22 +16,29 @@ class OracleEnv:
         self.init_q = init_q
         self.Nu = 2 if name == "car2d" else model_struct.n_act
 
-    def reset(self, key, impl):
-        """humanoidrun.py:19-32 / hopper.py:20-34 / humanoidtrack.py:48-61 / car2d.py:73-75"""
-        if self.name == "car2d":
-            return self.orc.car2d_reset()
+    def reset_qqd(self, key, impl):
+        """(q, qd) the env's reset hands to pipeline_init: humanoidrun.py:19-27 / hopper.py:20-28 / walker2d.py:19-27 /
+        humanoidstandup.py:19-27 / cartpole.py:20-28 (its [0, pi] offset is part of the compiled init_q) /
+        humanoidtrack.py:48-52 (deterministic); brax ant / half_cheetah: qvel = hi * normal(rng2)"""
         m = self.ms
         q = np.array(self.init_q, np.float32)
         qd = np.zeros(m.n_qd, np.float32)
         s = np.float32(m.reset_noise)
-        if s > 0:  # humanoidrun.py:21-27, hopper.py:22-28, walker2d.py:21-27, humanoidstandup.py:21-27
+        if s > 0:
             keys = self.orc.split(key, 3, impl)
             q = (q + self.orc.uniform(keys[1], m.n_q, -s, s, impl)).astype(np.float32)
-            if self.name in ("halfcheetah", "ant"):  # brax: qvel = hi * normal(rng2)
+            if self.name in ("halfcheetah", "ant"):
                 qd = (s * self.orc.normal(keys[2], (m.n_qd,), impl)).astype(np.float32)
             else:
                 qd = self.orc.uniform(keys[2], m.n_qd, -s, s, impl)
-        return self.orc.forward(m, q, qd)
+        return q, qd
+
+    def reset(self, key, impl):
+        """humanoidrun.py:19-32 / hopper.py:20-34 / humanoidtrack.py:48-61 / car2d.py:73-75"""
+        if self.name == "car2d":
+            return self.orc.car2d_reset()
+        q, qd = self.reset_qqd(key, impl)
+        return self.orc.forward(self.ms, q, qd)
 
     def rollout(self, state0, us, want_xpos=False):
         if self.name == "car2d":

@@ -201,3 +201,40 @@ def test_humanoidtrack_demo_matches_the_executed_reference(orc):
         lp = orc.track_xref_logpd(g["humanoidtrack_xpos"][b], mine)
         assert abs(float(lp) - float(g["humanoidtrack_logpd"][b])) < 1e-6, b
     assert g["humanoidtrack_logpd"].min() < -0.9 and g["humanoidtrack_logpd"].max() > -0.05   # (both ends of the clip)
+
+
+@pytest.mark.parametrize("name", ["humanoidrun", "hopper", "walker2d", "humanoidstandup", "cartpole", "humanoidtrack"])
+def test_env_resets_match_the_executed_reference(orc, name):
+    """The wrappers' own reset(rng), executed (which sub-key of split(rng, 3) perturbs q and which qd, the noise ranges per
+    env, cartpole's [0, pi] offset, humanoidtrack's deterministic reset): the (q, qd) they hand to Brax's pipeline_init
+    equal the checker's, exactly (same generator, same arithmetic: one float32 add per coordinate)."""
+    from conftest import load_model
+    from oracle import planner as op
+    g = np.load(os.path.join(GOLD, "ref_env_resets.npz"))
+    m = load_model(name)
+    env = op.OracleEnv(orc, name, m.to_struct(), init_q=m.init_q)
+    for seed in (0, 3):
+        q, qd = env.reset_qqd(g[f"{name}_key{seed}"], 1)
+        assert np.array_equal(q, g[f"{name}_q{seed}"]) and np.array_equal(qd, g[f"{name}_qd{seed}"]), (name, seed)
+    if name != "humanoidtrack":
+        assert not np.array_equal(g[f"{name}_q0"], g[f"{name}_q3"])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["humanoidrun", "hopper", "humanoidstandup", "cartpole"])
+def test_gpu_env_reset_matches_the_executed_reference(name):
+    """mbd_env_reset of the library: the generalized coordinates recovered from its state (mbd_model_observe: inverse
+    kinematics on the host) are the (q, qd) the reference's reset hands to pipeline_init, to 2e-5."""
+    from mbd_hip import _capi
+    from mbd_hip.envs import get_env
+    if _capi.device_count() < 1:
+        pytest.fail("GPU tests need a visible MI355X; the product has no CPU fallback")
+    g = np.load(os.path.join(GOLD, "ref_env_resets.npz"))
+    env = get_env(name)
+    for seed in (0, 3):
+        st = env.reset(g[f"{name}_key{seed}"])
+        q, qd = env.generalized(st.pipeline_state)
+        want = g[f"{name}_q{seed}"].astype(np.float64)
+        if int(env.sys.fields["n_rot"][0]) < 0:   # free root: the library normalises the perturbed quaternion (DESIGN.md §9:
+            want[3:7] /= np.linalg.norm(want[3:7])  # MBD_FLAG_RESET_QUAT_RAW keeps it raw), the reference hands it on as is
+        assert np.abs(q - want).max() < 2e-5 and np.abs(qd - g[f"{name}_qd{seed}"]).max() < 2e-4, (name, seed)

@@ -141,6 +141,8 @@ def make_jax(orc, impl):
         REC["cur"]["eps"] = np.array(eps, np.float32)
         return eps
     rnd.normal = normal
+    rnd.uniform = lambda key, shape, minval=0.0, maxval=1.0: _w(orc.uniform(np.asarray(key, np.uint32), int(np.prod(shape)),
+                                                                          float(minval), float(maxval), impl).reshape(shape))
     jax.random = rnd
     nn = types.ModuleType("jax.nn")
 
@@ -173,13 +175,20 @@ class _Any(types.ModuleType):
         return type(name, (_AnyBase,), {})
 
 
+class _Sys(types.SimpleNamespace):
+    def replace(self, **kw):      # (cartpole.py:18 sys.replace(dt=0.005))
+        d = dict(self.__dict__)
+        d.update(kw)
+        return _Sys(**d)
+
+
 def _fake_mjcf_load(path):
     """stands in for brax.io.mjcf.load where an env's constructor only asks the system for its link NAMES
     (humanoidtrack.py:26-31): bodies that own a joint, in document order — Brax's link order"""
     import xml.etree.ElementTree as ET
     names = []
     if not os.path.exists(str(path)):   # (hopper.py:13 / walker2d.py:14 load their XML from inside the Brax wheel)
-        return types.SimpleNamespace(link_names=names)
+        return _Sys(link_names=names)
 
     def walk(e):
         for b in e.findall("body"):
@@ -187,7 +196,7 @@ def _fake_mjcf_load(path):
                 names.append(b.get("name"))
             walk(b)
     walk(ET.parse(str(path)).getroot().find("worldbody"))
-    return types.SimpleNamespace(link_names=names)
+    return _Sys(link_names=names)
 
 
 def _reconstruct_array(fun, args, arr_state, aval_state):
@@ -340,6 +349,38 @@ def env_rewards():
     print(f"wrote {path}")
 
 
+def env_resets():
+    """The wrappers' own `reset(rng)` executed (humanoidrun.py:19-32, hopper.py:20-34, walker2d.py:19-33, humanoidstandup.py:19-32,
+    cartpole.py:20-37, humanoidtrack.py:48-61): which sub-key perturbs which coordinates, the noise ranges, cartpole's [0, pi]
+    offset — with `sys.init_q` / sizes handed in from this repo's compiled models and Brax's `pipeline_init` (forward
+    kinematics: not the reference's code) replaced by a recorder of the (q, qd) it is given."""
+    from mbd_hip.model import Model
+    out = {}
+    for mod, cls in (("humanoidrun", "HumanoidRun"), ("hopper", "Hopper"), ("walker2d", "Walker2d"),
+                     ("humanoidstandup", "HumanoidStandup"), ("cartpole", "Cartpole"), ("humanoidtrack", "HumanoidTrack")):
+        with open(os.path.join(ROOT, "model-based-diffusion_amd", "assets", "compiled", f"{mod}.json")) as f:
+            m = Model.from_json(f.read())
+        init_q = m.init_q.copy()
+        if mod == "cartpole":       # (the compiled model carries the reset offset of cartpole.py:26 in init_q already)
+            init_q = init_q - np.array([0.0, np.pi], np.float32)
+        env = getattr(importlib.import_module(f"mbd.envs.{mod}"), cls)()
+        env.sys = types.SimpleNamespace(init_q=_w(init_q), q_size=lambda m=m: m.q_size(), qd_size=lambda m=m: m.qd_size(),
+                                        act_size=lambda m=m: m.act_size())
+        got = {}
+
+        def pipeline_init(q, qd, got=got, L=m.n_links):
+            got["q"], got["qd"] = np.asarray(q, np.float32), np.asarray(qd, np.float32)
+            return types.SimpleNamespace(q=_w(got["q"]), qd=_w(got["qd"]), x=types.SimpleNamespace(pos=_w(np.zeros((L, 3), np.float32))))
+        env.pipeline_init = pipeline_init
+        for seed in (0, 3):
+            key = orc_key(seed)
+            env.reset(key)
+            out[f"{mod}_key{seed}"], out[f"{mod}_q{seed}"], out[f"{mod}_qd{seed}"] = key, got["q"], got["qd"]
+    path = os.path.join(ROOT, "tests", "golden", "ref_env_resets.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}")
+
+
 def main():
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     os.environ.setdefault("TQDM_DISABLE", "1")
@@ -355,6 +396,9 @@ def main():
     env_rollouts()
     pi_updates(orc)
     env_rewards()
+    global orc_key
+    orc_key = lambda seed: orc.split(orc.prng_key(seed), 2, 1)[1]   # rng_reset of mbd_planner.py:79
+    env_resets()
 
 
 if __name__ == "__main__":
