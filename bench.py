@@ -54,7 +54,6 @@ for p in (ROOT, os.path.join(ROOT, "model-based-diffusion_amd")):
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 VALU_PEAK_TF = 157.3   # MI355X_MICROARCH.md: vector FP32 peak
-ROUND = "r04"
 
 CONFIGS = {
     # name: env, N, H, Ndiffuse, temp, demo, lanes per candidate (rollout kernel), kernel label
