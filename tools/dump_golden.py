@@ -168,6 +168,7 @@ def dump_bounce(out):
 
 def main():
     ref, env_name, N, H, steps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    sys.dont_write_bytecode = True  # importing the reference must not leave __pycache__ in its tree
     sys.path.insert(0, ref)
     import functools
     import brax

@@ -24,6 +24,8 @@ import types
 
 import numpy as np
 
+sys.dont_write_bytecode = True  # the reference tree is read-only to this repo: importing from it must not leave __pycache__ there
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "model-based-diffusion_amd")):
     if p not in sys.path:
