@@ -221,6 +221,13 @@ int mbd_env_info(const mbd_env* env, int* action_size, int* observation_size, in
 /* reset(rng) -> state (humanoidrun.py:19-32, hopper.py:20-34, humanoidtrack.py:48-61, car2d.py:73-75).
  * Host computation (forward kinematics once per run). state_out: float[state_size] HOST. */
 int mbd_env_reset(const mbd_env* env, const uint32_t key[2], int prng_impl, float* state_out);
+/* PipelineEnv.pipeline_init(q, qd) -> pipeline_state (the call every wrapper's reset ends in: humanoidrun.py:29,
+ * hopper.py:30, walker2d.py:29, humanoidstandup.py:29, cartpole.py:29, humanoidtrack.py:54): forward kinematics of the
+ * generalized coordinates — a state to plan FROM that is not a reset (receding-horizon use).  q: float[n_q] (free root:
+ * position, quaternion w-first — normalised like reset's unless MBD_FLAG_RESET_QUAT_RAW), qd: float[n_qd]; n_q / n_qd must
+ * be the model's (mbd_env_get_model).  car2d: q = (x, y, theta), n_q = 3, qd ignored (may be NULL, n_qd = 0).  Host
+ * arithmetic, no device needed; all pointers HOST. */
+int mbd_env_pipeline_init(const mbd_env* env, const float* q, int n_q, const float* qd, int n_qd, float* state_out);
 /* step(state, action) -> (state', reward, obs) for ONE environment (rendering / verification path,
  * mbd_planner.py:163; utils.py:23-33).  Runs the same HIP rollout kernel with B=1,H=1; synchronous.
  * All pointers HOST. reward_out / obs_out (float[observation_size], see mbd_env_observe) may be NULL. */
@@ -246,6 +253,10 @@ int mbd_env_observe(const mbd_env* env, const float* state, float* obs_out);
 /* the same from a bare model, plus the generalized coordinates: q_out[n_q], qd_out[n_qd], obs_out — any may be
  * NULL.  Pure host arithmetic, no device needed. */
 int mbd_model_observe(const mbd_model_t* model, const float* state, float* q_out, float* qd_out, float* obs_out);
+
+/* pipeline_init from a bare model (the inverse of mbd_model_observe's q_out / qd_out): q[model->n_q], qd[model->n_qd] ->
+ * state_out[13 * n_links].  Pure host arithmetic, no device needed. */
+int mbd_model_forward(const mbd_model_t* model, const float* q, const float* qd, float* state_out);
 
 /* Batched rollout = jax.vmap(rollout_us, in_axes=(None,0)) (mbd_planner.py:109, utils.py:14-20).
  *   d_state0 : [state_size]        one initial state shared by all B candidates

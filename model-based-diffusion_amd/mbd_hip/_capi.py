@@ -37,7 +37,7 @@ class PlanConfig(C.Structure):
 EXPORTS = [
     "mbd_last_error", "mbd_version", "mbd_device_count", "mbd_prng_key", "mbd_prng_split",
     "mbd_env_create", "mbd_env_name", "mbd_builtin_model", "mbd_env_get_model", "mbd_env_xref", "mbd_env_xref_logpd",
-    "mbd_env_observe", "mbd_model_observe", "mbd_env_create_car2d", "mbd_env_create_model", "mbd_env_destroy", "mbd_env_info", "mbd_env_reset",
+    "mbd_env_observe", "mbd_model_observe", "mbd_model_forward", "mbd_env_create_car2d", "mbd_env_create_model", "mbd_env_destroy", "mbd_env_info", "mbd_env_reset", "mbd_env_pipeline_init",
     "mbd_env_step", "mbd_env_rew_xref", "mbd_env_rollout", "mbd_plan_create", "mbd_plan_destroy",
     "mbd_plan_schedule", "mbd_plan_set_state0", "mbd_plan_sample_rollout", "mbd_plan_prefetch_noise", "mbd_plan_score_update",
     "mbd_plan_set_sigma", "mbd_plan_get_sigma", "mbd_plan_reverse_once", "mbd_plan_run", "mbd_plan_eval", "mbd_plan_peek", "mbd_plan_kernel_time",
@@ -88,6 +88,8 @@ def load() -> C.CDLL:
     lib.mbd_env_destroy.argtypes = [_vp]
     lib.mbd_env_info.argtypes = [_vp] + [C.POINTER(_i)] * 5 + [_fp]
     lib.mbd_env_reset.argtypes = [_vp, _u32p, _i, _vp]
+    lib.mbd_model_forward.argtypes = [_vp, _vp, _vp, _vp]
+    lib.mbd_env_pipeline_init.argtypes = [_vp, _vp, _i, _vp, _i, _vp]
     lib.mbd_env_step.argtypes = [_vp, _vp, _vp, _vp, _vp, _vp]
     lib.mbd_env_rew_xref.argtypes = [_vp, _fp]
     lib.mbd_env_rollout.argtypes = [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp]

@@ -78,6 +78,16 @@ class _EnvBase:
         _capi.check(self._lib.mbd_env_reset(self._h, _capi.key_array(rng), prng_impl(), _capi.np_ptr(st)))
         return State(self._shape_state(st), self.observe(st), np.float32(0.0), np.float32(0.0), {})
 
+    def pipeline_init(self, q, qd=None):
+        """PipelineEnv.pipeline_init(q, qd) (humanoidrun.py:29): the pipeline state of generalized coordinates — what
+        ``Plan.set_state0`` / ``rollout_us`` take; a state to plan from that is not a reset."""
+        q = np.ascontiguousarray(q, np.float32).reshape(-1)
+        qd = np.zeros(0, np.float32) if qd is None else np.ascontiguousarray(qd, np.float32).reshape(-1)
+        st = np.zeros(self._state_size, np.float32)
+        _capi.check(self._lib.mbd_env_pipeline_init(self._h, _capi.np_ptr(q), q.size, _capi.np_ptr(qd) if qd.size else None,
+                                                    qd.size, _capi.np_ptr(st)))
+        return self._shape_state(st)
+
     def step(self, state: State, action) -> State:
         s_in = np.ascontiguousarray(state.pipeline_state, np.float32).reshape(-1)
         a = np.ascontiguousarray(action, np.float32).reshape(-1)

@@ -553,6 +553,42 @@ def test_env_step_produces_observations(gpu):
         assert st2.obs.shape == (env.observation_size,) and np.isfinite(st2.obs).all()
 
 
+@pytest.mark.parametrize("name", ["humanoidrun", "hopper", "ant", "car2d"])
+def test_pipeline_init_is_the_checkers_forward_kinematics_and_plans_start_from_it(gpu, orc, name):
+    """PipelineEnv.pipeline_init(q, qd) through the C ABI (mbd_env_pipeline_init): bit-equal to the checker's forward
+    kinematics; a rollout from that state is the checker's, bit for bit; wrong sizes are refused."""
+    import torch
+    from conftest import load_model
+    from mbd_hip.envs import get_env
+    from mbd_hip.envs.base import State
+    env = get_env(name)
+    g = np.random.default_rng(3)
+    if name == "car2d":
+        q = np.array([-0.3, 0.2, 1.0], np.float32)
+        ps = env.pipeline_init(q)
+        assert np.array_equal(np.asarray(ps).reshape(-1), q)
+        us = g.uniform(-1, 1, (8, 12, 2)).astype(np.float32)
+        rew = env.rollout(State(ps, None, 0.0, 0.0, {}), us).cpu().numpy()
+        assert np.array_equal(rew, orc.car2d_rollout(q, us))
+        with pytest.raises(Exception):
+            env.pipeline_init(np.zeros(4, np.float32))
+        return
+    m = load_model(name)
+    ms = m.to_struct()
+    q = (m.init_q + g.uniform(-0.05, 0.05, m.q_size())).astype(np.float32)
+    qd = g.uniform(-0.5, 0.5, m.qd_size()).astype(np.float32)
+    ps = env.pipeline_init(q, qd)
+    want = orc.forward(ms, q, qd)
+    assert np.array_equal(np.asarray(ps, np.float32).reshape(want.shape), want)
+    us = g.uniform(-1, 1, (16, 6, env.action_size)).astype(np.float32)
+    rew = env.rollout(State(ps, None, 0.0, 0.0, {}), us).cpu().numpy()
+    assert np.array_equal(rew, orc.rollout(ms, want, us))
+    with pytest.raises(Exception):
+        env.pipeline_init(q[:-1], qd)
+    with pytest.raises(Exception):
+        env.pipeline_init(q)
+
+
 def test_render_outputs_mu0ts_and_replay(gpu, tmp_path, monkeypatch):
     """N1: without not_render the run leaves results/{env}/mu_0ts.npy (the array vis_diffusion.py:22 loads)
     and the replayed final plan; replaying through env.step equals the batched rollout kernel."""

@@ -238,3 +238,31 @@ def test_gpu_env_reset_matches_the_executed_reference(name):
         if int(env.sys.fields["n_rot"][0]) < 0:   # free root: the library normalises the perturbed quaternion (DESIGN.md §9:
             want[3:7] /= np.linalg.norm(want[3:7])  # MBD_FLAG_RESET_QUAT_RAW keeps it raw), the reference hands it on as is
         assert np.abs(q - want).max() < 2e-5 and np.abs(qd - g[f"{name}_qd{seed}"]).max() < 2e-4, (name, seed)
+
+
+@pytest.mark.parametrize("name", ["humanoidrun", "hopper", "walker2d", "humanoidstandup", "cartpole", "humanoidtrack"])
+def test_observations_match_the_executed_reference(orc, lib, name):
+    """The wrappers' own `_get_obs`, executed, on states with known (q, qd): the library's pipeline_init
+    (mbd_model_forward — host arithmetic, no device) followed by its `_get_obs` (mbd_model_observe: inverse kinematics) gives
+    the reference's observation — layout, hopper's / walker2d's torso height in slot 1 and their +-10 clip of qd included.
+    Case a (angles off rest, qd = 0): 3e-5.  Case b (rest pose, |qd| up to 15): 1e-4 relative to 15; at the rest pose the
+    multi-dof joints' rate map is the identity, so the humanoids' qd compare too.  The forward kinematics itself is
+    bit-equal to the checker's."""
+    import ctypes as C
+    from conftest import load_model
+    g = np.load(os.path.join(GOLD, "ref_env_obs.npz"))
+    m = load_model(name)
+    ms = m.to_struct()
+    clipped = False
+    for tag, tol in (("a", 3e-5), ("b", 1.5e-3)):
+        q, qd, want = g[f"{name}_{tag}_q"], g[f"{name}_{tag}_qd"], g[f"{name}_{tag}_obs"]
+        st = np.zeros((m.n_links, 13), np.float32)
+        assert lib.mbd_model_forward(C.byref(ms), q.ctypes.data, qd.ctypes.data, st.ctypes.data) == 0
+        assert np.array_equal(st, orc.forward(ms, q, qd))
+        obs = np.zeros(want.size, np.float32)
+        assert lib.mbd_model_observe(C.byref(ms), st.ctypes.data, None, None, obs.ctypes.data) == 0
+        d = np.abs(obs - want)
+        d[:q.size] = np.minimum(d[:q.size], np.abs(d[:q.size] - np.float32(2 * np.pi)))   # (a hinge at pi — cartpole's rest
+        assert d.max() < tol, (name, tag, d.max())                                        # pose — may come back as -pi)
+        clipped |= bool(np.abs(qd).max() > 10.0 and np.abs(want[q.size:]).max() <= 10.0)
+    assert clipped == (name in ("hopper", "walker2d"))

@@ -383,6 +383,48 @@ def env_resets():
     print(f"wrote {path}")
 
 
+def env_obs(orc):
+    """The wrappers' own `_get_obs` executed (humanoidrun.py:43-44, hopper.py:49-55, walker2d.py:50-56, humanoidstandup.py,
+    cartpole.py:54-56, humanoidtrack.py:84-85) on a pipeline state with given q, qd and — for the two that read it — the
+    torso origin's height `x.pos[0, 2]` (from this repo's forward kinematics: an INPUT here, not the reference's code).
+    Two states per env: joint angles off their rest values with qd = 0, and the rest pose with |qd| up to 15 (beyond
+    hopper's / walker2d's +-10 clip)."""
+    from mbd_hip.model import Model
+    out = {}
+    g = np.random.default_rng(11)
+    for mod, cls in (("humanoidrun", "HumanoidRun"), ("hopper", "Hopper"), ("walker2d", "Walker2d"),
+                     ("humanoidstandup", "HumanoidStandup"), ("cartpole", "Cartpole"), ("humanoidtrack", "HumanoidTrack")):
+        with open(os.path.join(ROOT, "model-based-diffusion_amd", "assets", "compiled", f"{mod}.json")) as f:
+            m = Model.from_json(f.read())
+        ms = m.to_struct()
+        env = getattr(importlib.import_module(f"mbd.envs.{mod}"), cls)()
+        env.sys = types.SimpleNamespace(act_size=lambda m=m: m.act_size())
+        q_a = m.init_q.copy()
+        for l in range(m.n_links):
+            if m.fields["n_rot"][l] < 0:
+                continue
+            qi, ns = int(m.fields["q_idx"][l]), int(m.fields["n_slide"][l])
+            for k in range(int(m.fields["n_rot"][l])):
+                sg = float(m.fields["rot_sign"][l][k])
+                lo, hi = sorted((sg * max(m.fields["rot_lo"][l][k], -0.6), sg * min(m.fields["rot_hi"][l][k], 0.6)))
+                q_a[qi + ns + k] = g.uniform(lo, hi) * 0.5
+            for k in range(ns):
+                q_a[qi + k] += g.uniform(-0.2, 0.2)
+        cases = {"a": (q_a.astype(np.float32), np.zeros(m.qd_size(), np.float32)),
+                 "b": (m.init_q.astype(np.float32), g.uniform(-15, 15, m.qd_size()).astype(np.float32))}
+        for tag, (q, qd) in cases.items():
+            xpos = orc.link_positions(ms, orc.forward(ms, q, qd))
+            ps = types.SimpleNamespace(q=_w(q), qd=_w(qd), x=types.SimpleNamespace(pos=_w(xpos)))
+            try:
+                obs = env._get_obs(ps)
+            except TypeError:  # (humanoidrun / humanoidstandup: _get_obs(pipeline_state, action))
+                obs = env._get_obs(ps, _w(np.zeros(m.act_size(), np.float32)))
+            out[f"{mod}_{tag}_q"], out[f"{mod}_{tag}_qd"], out[f"{mod}_{tag}_obs"] = q, qd, np.asarray(obs, np.float32)
+    path = os.path.join(ROOT, "tests", "golden", "ref_env_obs.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}")
+
+
 def main():
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     os.environ.setdefault("TQDM_DISABLE", "1")
@@ -401,6 +443,7 @@ def main():
     global orc_key
     orc_key = lambda seed: orc.split(orc.prng_key(seed), 2, 1)[1]   # rng_reset of mbd_planner.py:79
     env_resets()
+    env_obs(orc)
 
 
 if __name__ == "__main__":
