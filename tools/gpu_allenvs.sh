@@ -17,4 +17,13 @@ for meth in ("mppi", "cma-es", "cem"):
     a = PArgs(seed=0, env_name="hopper", update_method=meth)
     r, d = run_path_integral(a, return_details=True)
     print("path_integral %-7s hopper: rew %.3f sigma_final %.4f" % (meth, r, d["sigma_final"]))
+# the reference's own sweeps with its default arguments (mbd/scripts/run_mbd.py:17-64): 8 seeds / 8 temperatures
+from mbd_hip.scripts import run_mbd
+for env in ("hopper", "ant", "humanoidrun"):
+    t = time.time(); rews, secs = run_mbd.run_multiple_seed(run_mbd.Args(algo="mbd", mode="seed", env_name=env)); dt = time.time() - t
+    print("run_multiple_seed mbd %-12s: rews %s  (%.2f s of lockstep loop, %.2f s wall)" % (env, np.round(rews, 3), secs, dt))
+rews, secs = run_mbd.run_multiple_seed(run_mbd.Args(algo="path_integral", update_method="cma-es", mode="seed", env_name="hopper"))
+print("run_multiple_seed path_integral cma-es hopper: rews %s (%.2f s)" % (np.round(rews, 3), secs))
+rews, best = run_mbd.run_multiple_temp(run_mbd.Args(algo="mbd", mode="temp", env_name="hopper"))
+print("run_multiple_temp mbd hopper: best_temp %.2f" % best)
 PY
