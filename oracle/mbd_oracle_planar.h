@@ -82,14 +82,6 @@ static void pl_setup(const mbd_model_t* m, plink_t* k) {
   }
 }
 
-/* world position of the link-frame origin (x, z): p - R com */
-static void pl_origin(const mbd_model_t* m, int l, const pxf_t* x, real* ox, real* oz) {
-  pcs_t a = pl_cs(x[l].qw, x[l].qy);
-  real tx, tz;
-  pl_rot(a, R(m->com[l][0]), R(m->com[l][2]), &tx, &tz);
-  *ox = x[l].px - tx; *oz = x[l].pz - tz;
-}
-
 static void substep_planar(const mbd_model_t* m, pxf_t* x, pmo_t* xd, const real* tau_rot, const real* tau_slide,
                            float* stage_dump) {
   const int L = m->n_links;
