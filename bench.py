@@ -379,12 +379,13 @@ def main():
             keys.append(_capi.prng_split(rng, 2)[0])  # rng_exp (:150)
         return np.array(keys, np.uint32), states
 
-    def measure_sweep(seeds, steps=None, warmup=None, repeats=None):
+    def measure_sweep(seeds, steps=None, warmup=None, repeats=None, local=False):
         """config sweep8: blocks of K lockstep diffusion steps of the plans with these seeds (mbd_sweep_run with
         Ndiffuse = K + 1, no host outputs: the timed region is the K steps and nothing else).  No per-step host read: the
         reference's sweep prints nothing per step either (not_render runs of run_diffusion keep their progress bar, but
         the sweep's measure is the time of whole runs).  Returns (seconds of every block — max over ranks —, average
-        rollout-launch ms, launches, this rank's own seconds per block)."""
+        rollout-launch ms, launches, this rank's own seconds per block).  local=True: no fence between the ranks and no
+        reduction — this rank's own clock only (a rank that fails cannot leave the others waiting)."""
         from mbd_hip.planners.mbd_planner import Sweep
         P = len(seeds)
         steps, warmup = steps or args.steps, (args.warmup if warmup is None else warmup)
@@ -406,11 +407,17 @@ def main():
                 done += steps
             blocks, own = [], []
             for _ in range(repeats):
-                fence()
+                if local:
+                    torch.cuda.synchronize(dev)
+                else:
+                    fence()
                 t0 = time.perf_counter()
                 sw.run(keys, outputs=False)
                 torch.cuda.synchronize(dev)
                 own.append(time.perf_counter() - t0)
+                if local:
+                    blocks.append(own[-1])
+                    continue
                 fence()
                 blocks.append(max_over_ranks(time.perf_counter() - t0))
             sw.kernel_time(enable=True)
@@ -699,6 +706,28 @@ def main():
                 extras[name] = fn()
             except Exception as e:  # noqa: BLE001 — extras never cost the line its value
                 extras[name] = {"error": f"{type(e).__name__}: {e}"}
+
+    # With G > 1 ranks the metric's own curve is flat by construction (a rollout is latency-bound: N / G candidates take as
+    # long as N).  The workload of the reference that DOES scale — its 8-seed sweep, plans as replicas — rides in the
+    # same line: every rank runs 8 plans of N = 1024 (its own seeds) as one sweep on its GPU, no collective inside and no
+    # fence between the ranks; ONE gather of the per-rank rates at the end, reached by every rank whatever happened.
+    if distributed and world > 1 and args.config == "metric" and not args.no_extras and not os.environ.get("MBD_BENCH_N"):
+        try:
+            P_x = CONFIGS["sweep8"]["plans"]
+            _, x_kms, _, x_own = measure_sweep(list(range(rank * P_x, (rank + 1) * P_x)), steps=40, warmup=5, repeats=3,
+                                               local=True)
+            mine = {"plan_steps_per_sec": P_x * 40 / med(x_own), "kernel_avg_ms": x_kms}
+        except Exception as e:  # noqa: BLE001 — extras never cost the line its value
+            mine = {"error": f"{type(e).__name__}: {e}"}
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+        if rank == 0:
+            good = [b for b in box if isinstance(b, dict) and "plan_steps_per_sec" in b]
+            extras = {"sweep8_replicas": {
+                "workload": f"8 plans x humanoidrun N=1024 H=50 per GPU as one sweep each ({world} GPUs, {8 * world} plans), 40 "
+                            "steps of mbd_sweep_run, median of 3 runs per rank; SUM of the ranks' own rates (no fence, no "
+                            "collective: the plans are independent replicas) — `--config sweep8 --gpus G` is the fenced form",
+                "plan_steps_per_sec": sum(b["plan_steps_per_sec"] for b in good), "ranks_ok": len(good), "per_rank": box}}
 
     per_rank = None
     if is_sweep and distributed:  # every rank's own rate (its plans, its clock), for the line

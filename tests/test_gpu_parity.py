@@ -858,6 +858,9 @@ def test_bench_eight_ranks_lines_are_complete(gpu, config, n_strong):
     assert set(d["phase_ms"]) >= {"phase1_ms", "exchange_ms", "phase2_ms"} and d["phase_ms"]["phase1_ms"] > 0.1
     assert d["other_collective"]["collective"].startswith("p2p") and d["other_collective"]["value"] > 10.0, d["other_collective"]
     assert d["other_scaling"]["scaling"] == "weak" and d["other_scaling"]["N_per_gpu"] == 8 * n_strong
+    if config == "metric":  # the workload that scales rides in the same line: 8 plans per rank as one sweep each, rates summed
+        x = d["extras"]["sweep8_replicas"]
+        assert x["ranks_ok"] == 8 and len(x["per_rank"]) == 8 and x["plan_steps_per_sec"] > 100.0, x
 
 
 @pytest.mark.parametrize("world", [2, 8])
