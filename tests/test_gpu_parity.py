@@ -166,6 +166,29 @@ def test_custom_mjcf_model_on_the_general_kernels(gpu, orc, no_dpp, monkeypatch,
     _one_step(gpu, orc, "hopper", 96, 12, 20, 0.1, 1, False, i=12, env=env)
 
 
+@pytest.mark.parametrize("seed", range(16))
+def test_random_models_on_the_general_kernels(gpu, orc, seed, levers):
+    """Fuzz (tests/random_models.py): random link trees — 1 / 2 / 3-dof hinges, slide + hinge joints, fused bodies, up to four
+    children and two colliders on a link, both inertia classes, springs, dampers, restitution — through mjcf.load ->
+    mbd_env_create_model -> whichever general instantiation the library picks (every third seed with the DPP layouts off):
+    rollouts and one planning step, bit for bit."""
+    from random_models import stable_random_model
+    from test_random_models import _comp
+    from mbd_hip.envs.base import RigidBodyEnv
+    if seed % 3 == 2:
+        levers(MBD_NO_DPP=1)
+    _, m = stable_random_model(seed, _comp)
+    env = RigidBodyEnv("hopper", model=m)
+    st = env.reset(gpu.prng_key(seed))
+    rng = np.random.default_rng(seed)
+    us = np.clip(rng.normal(size=(37, 30, env.action_size)) * 0.6, -1.3, 1.3).astype(np.float32)
+    got = env.rollout(st, us).cpu().numpy()
+    ref = _oenv(orc, env).rollout(np.asarray(st.pipeline_state, np.float32), us)
+    assert np.isfinite(got).all() and np.ptp(got) > 1e-4
+    assert np.array_equal(got, ref), f"seed {seed}: max |d| = {np.abs(got - ref).max()}"
+    _one_step(gpu, orc, "hopper", 64, 10, 20, 0.1, 1, False, i=10, env=env)
+
+
 @pytest.mark.parametrize("planar", [None, False])
 def test_custom_planar_model_sixteen_lane_groups(gpu, orc, planar):
     """tests/custom_models.py TRIPOD: a planar model of ten links — a 16-lane candidate group, which no built-in planar
