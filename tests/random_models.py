@@ -15,7 +15,9 @@ def _v(x):
 
 
 def random_mjcf(seed, max_bodies=14, kinds=("h1", "h1", "h2", "h3", "sh", "none"), probs=(0.3, 0.2, 0.2, 0.12, 0.1, 0.08),
-                springs=True, sis=(0, 0.5, 1.0)):
+                springs=True, sis=(0, 0.5, 1.0), planar=False):
+    """planar=True: a model that moves in the x-z plane only (root = slide x, slide z, hinge y like hopper / walker2d /
+    halfcheetah; every other joint one hinge about +-y; geoms in the plane) — what the planar kernels take."""
     g = np.random.default_rng(seed)
     n_bodies = int(g.integers(min(3, max_bodies), max_bodies + 1))
     parent, depth, kids = [-1], [0], [0]
@@ -23,17 +25,19 @@ def random_mjcf(seed, max_bodies=14, kinds=("h1", "h1", "h2", "h3", "sh", "none"
         cand = [p for p in range(b) if kids[p] < (4 if p == 0 else 3) and depth[p] < 5]
         p = int(g.choice(cand))
         parent.append(p); depth.append(depth[p] + 1); kids.append(0); kids[p] += 1
+    sis_v = float(g.choice(list(sis)))
     # a capsule per body from its origin to a tip; children hang at the tip or half way
     tip, rad = [], []
     for b in range(n_bodies):
-        d = g.normal(size=3) * np.array([1.0, 1.0, 0.6]) + (np.array([0, 0, -1.0]) if b else 0)
+        d = g.normal(size=3) * np.array([1.0, 0.0 if planar else 1.0, 0.6]) + (np.array([0, 0, -1.0]) if b else 0)
+        if planar and sis_v < 1.0:   # (the planar restatement wants diagonal tensors: true tensors of axis-aligned capsules, or
+            d = np.array([[1.0, 0, 0], [-1.0, 0, 0], [0, 0, -1.0]][int(g.integers(0, 3 if b else 2))])   # spring_inertia_scale = 1)
         d = d / np.linalg.norm(d) * g.uniform(0.14, 0.32)
         # (parents heavier than their children: the joint stage sums the corrections of ALL joints of a link, Jacobi-style;
         # a light link between heavy neighbours overshoots — e.g. 4 joints x joint_scale_pos 0.7 on a 1.5 kg root carrying
         # 2-5 kg children diverges in free fall — which is why the reference's models have heavy torsos and scales 0.5 / 0.2)
         tip.append(d); rad.append(float(g.uniform(0.085, 0.1) if b == 0 else g.uniform(0.03, 0.06) * 0.85 ** depth[b]))
     n_col, n_act_max = 0, 22
-    sis_v = float(g.choice(list(sis)))
     # explicit dampers and motors are stable only below ~2 I / dt: with spring_inertia_scale = 1 every tensor is the identity
     # (1 kg m^2, what the reference's humanoids use with constraint_ang_damping = 30); below it a thin capsule's axial inertia
     # is ~5e-4 kg m^2 and the same coefficients are far outside the stable range of ANY explicit integrator
@@ -46,14 +50,19 @@ def random_mjcf(seed, max_bodies=14, kinds=("h1", "h1", "h2", "h3", "sh", "none"
         pad = " " * indent
         pos = np.array([0.0, 0.0, 0.45 + 0.3 * max(depth)]) if b == 0 else tip[parent[b]] * (1.0 if g.random() < 0.7 else 0.5)
         out = [f'{pad}<body name="b{b}" pos="{_v(pos)}">']
-        if b == 0:
+        if b == 0 and planar:
+            out += [f'{pad} <joint name="rootx" type="slide" axis="1 0 0"/>', f'{pad} <joint name="rootz" type="slide" axis="0 0 1"/>',
+                    f'{pad} <joint name="rooty" type="hinge" axis="0 1 0"/>']
+        elif b == 0:
             out.append(f'{pad} <joint type="free"/>')
         else:
-            kind = g.choice(list(kinds), p=np.asarray(probs) / np.sum(probs))
+            kind = "p1" if planar else g.choice(list(kinds), p=np.asarray(probs) / np.sum(probs))
             if kind == "none" and any(parent[c] == b for c in range(n_bodies)):
                 kind = "h1"   # (a fused body in the middle of a chain would move its children onto the grandparent's link)
             js = []
-            if kind == "h1":
+            if kind == "p1":
+                js.append(("hinge", np.array([0, 1.0 if g.random() < 0.5 else -1.0, 0])))
+            elif kind == "h1":
                 a = g.normal(size=3); a /= np.linalg.norm(a)
                 js.append(("hinge", a))
             elif kind == "h2":

@@ -190,6 +190,25 @@ def test_random_models_on_the_general_kernels(gpu, orc, seed, levers):
 
 
 @pytest.mark.parametrize("planar", [None, False])
+@pytest.mark.parametrize("seed", range(8))
+def test_random_planar_models(gpu, orc, seed, planar):
+    """Fuzz, planar variant: random planar trees of 3..10 links (4-, 8- and 16-lane candidate groups) through the planar
+    kernels (planar=None) and, compiled planar=False, through the general 3-D axisymmetric / full-tensor instantiations."""
+    from random_models import stable_random_model
+    from test_random_models import _comp
+    from mbd_hip.envs.base import RigidBodyEnv
+    _, m = stable_random_model(seed, lambda x: _comp(x, env_name="halfcheetah", planar=planar), planar=True, max_bodies=10)
+    assert bool(int(m.fields["flags"]) & 2) == (planar is None)
+    env = RigidBodyEnv("halfcheetah", model=m)
+    st = env.reset(gpu.prng_key(seed))
+    us = np.clip(np.random.default_rng(seed).normal(size=(29, 30, env.action_size)) * 0.6, -1.3, 1.3).astype(np.float32)
+    got = env.rollout(st, us).cpu().numpy()
+    ref = _oenv(orc, env).rollout(np.asarray(st.pipeline_state, np.float32), us)
+    assert np.isfinite(got).all() and np.array_equal(got, ref), f"seed {seed}: max |d| = {np.abs(got - ref).max()}"
+    _one_step(gpu, orc, "halfcheetah", 48, 8, 20, 0.4, 1, False, i=10, env=env)
+
+
+@pytest.mark.parametrize("planar", [None, False])
 def test_custom_planar_model_sixteen_lane_groups(gpu, orc, planar):
     """tests/custom_models.py TRIPOD: a planar model of ten links — a 16-lane candidate group, which no built-in planar
     model needs — with joint springs, a limited root slide and restitution all at once (the planar kernel's run-time

@@ -43,6 +43,30 @@ def test_random_model_matches_the_independent_reader_and_rolls_out(orc, seed, tm
     assert np.ptp(rew) > 1e-4
 
 
+@pytest.mark.parametrize("seed", range(12))
+def test_random_planar_model_matches_the_independent_reader_and_rolls_out(orc, seed, tmp_path):
+    """the planar variant (root slide x, slide z, hinge y; hinges about +-y): qualifies for the planar restatement, agrees
+    with the independent reader, rolls out finite — as the planar restatement and, compiled planar=False, in 3-D
+    arithmetic (the two agree to round-off, not to the bit: different operation orders)"""
+    from oracle import model_reader
+    from test_model_crosscheck import _compare
+    xml, m = stable_random_model(seed, lambda x: _comp(x, env_name="halfcheetah"), planar=True, max_bodies=10)
+    assert int(m.fields["flags"]) & 2
+    f = tmp_path / "m.xml"
+    f.write_text(xml)
+    _compare(orc, f"planar{seed}", m, model_reader.read(str(f)), spec=SPEC)
+    m3 = _comp(xml, env_name="halfcheetah", planar=False)
+    us = np.clip(np.random.default_rng(seed).normal(size=(3, 40, m.act_size())) * 0.6, -1.3, 1.3).astype(np.float32)
+    rews = []
+    for mm in (m, m3):
+        ms = mm.to_struct()
+        st = orc.forward(ms, mm.init_q, np.zeros(mm.qd_size(), np.float32))
+        rew, fin = orc.rollout(ms, st, us, want_final=True)
+        assert np.isfinite(rew).all() and np.abs(fin[:, :, 7:]).max() < 2e3
+        rews.append(rew)
+    assert np.abs(rews[0][:, :5] - rews[1][:, :5]).max() < 1e-3   # (before chaos: the first control steps)
+
+
 def test_the_generator_covers_the_subset():
     """every joint kind, fused bodies, four children on a link, two colliders on a link, both inertia classes"""
     seen = set()

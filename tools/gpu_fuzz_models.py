@@ -1,5 +1,5 @@
 """Fuzz beyond the committed seeds: random MJCF models (tests/random_models.py) through the general kernels against the checker,
-rollouts bit for bit.  usage (GPU box): python tools/gpu_fuzz_models.py FIRST COUNT"""
+rollouts bit for bit.  usage (GPU box): python tools/gpu_fuzz_models.py FIRST COUNT [planar | planar3d]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "model-based-diffusion_amd"), os.path.join(ROOT, "tests")):
@@ -13,12 +13,17 @@ from oracle import oracle as orc_mod
 orc_mod.build()
 orc = orc_mod.Oracle("f32")
 first, count = int(sys.argv[1]), int(sys.argv[2])
+mode = sys.argv[3] if len(sys.argv) > 3 else "3d"
 bad = refused = 0
 kinds = {}
 for seed in range(first, first + count):
-    _, m = stable_random_model(seed, _comp)
+    if mode == "3d":
+        _, m = stable_random_model(seed, _comp)
+    else:
+        _, m = stable_random_model(seed, lambda x: _comp(x, env_name="halfcheetah", planar=None if mode == "planar" else False),
+                                   planar=True, max_bodies=10)
     try:
-        env = RigidBodyEnv("hopper", model=m)
+        env = RigidBodyEnv("hopper" if mode == "3d" else "halfcheetah", model=m)
     except Exception as e:  # a shape the library refuses (says so)
         refused += 1
         print(seed, "refused:", str(e)[:120])
@@ -30,4 +35,4 @@ for seed in range(first, first + count):
     if not np.array_equal(got, ref):
         bad += 1
         print(seed, "MISMATCH max|d|", np.abs(got - ref).max(), "links", m.n_links)
-print(f"seeds {first}..{first + count - 1}: {bad} mismatches, {refused} refused")
+print(f"{mode} seeds {first}..{first + count - 1}: {bad} mismatches, {refused} refused")
