@@ -171,7 +171,7 @@ def test_random_models_on_the_general_kernels(gpu, orc, seed, levers):
     """Fuzz (tests/random_models.py): random link trees — 1 / 2 / 3-dof hinges, slide + hinge joints, fused bodies, up to four
     children and two colliders on a link, both inertia classes, springs, dampers, restitution — through mjcf.load ->
     mbd_env_create_model -> whichever general instantiation the library picks (every third seed with the DPP layouts off):
-    rollouts and one planning step, bit for bit."""
+    rollouts long enough to hit the ground (90 control steps) and one planning step, bit for bit."""
     from random_models import stable_random_model
     from test_random_models import _comp
     from mbd_hip.envs.base import RigidBodyEnv
@@ -181,7 +181,7 @@ def test_random_models_on_the_general_kernels(gpu, orc, seed, levers):
     env = RigidBodyEnv("hopper", model=m)
     st = env.reset(gpu.prng_key(seed))
     rng = np.random.default_rng(seed)
-    us = np.clip(rng.normal(size=(37, 30, env.action_size)) * 0.6, -1.3, 1.3).astype(np.float32)
+    us = np.clip(rng.normal(size=(37, 90, env.action_size)) * 0.6, -1.3, 1.3).astype(np.float32)
     got = env.rollout(st, us).cpu().numpy()
     ref = _oenv(orc, env).rollout(np.asarray(st.pipeline_state, np.float32), us)
     assert np.isfinite(got).all() and np.ptp(got) > 1e-4
@@ -201,7 +201,7 @@ def test_random_planar_models(gpu, orc, seed, planar):
     assert bool(int(m.fields["flags"]) & 2) == (planar is None)
     env = RigidBodyEnv("halfcheetah", model=m)
     st = env.reset(gpu.prng_key(seed))
-    us = np.clip(np.random.default_rng(seed).normal(size=(29, 30, env.action_size)) * 0.6, -1.3, 1.3).astype(np.float32)
+    us = np.clip(np.random.default_rng(seed).normal(size=(29, 90, env.action_size)) * 0.6, -1.3, 1.3).astype(np.float32)
     got = env.rollout(st, us).cpu().numpy()
     ref = _oenv(orc, env).rollout(np.asarray(st.pipeline_state, np.float32), us)
     assert np.isfinite(got).all() and np.array_equal(got, ref), f"seed {seed}: max |d| = {np.abs(got - ref).max()}"

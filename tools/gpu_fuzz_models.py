@@ -1,5 +1,5 @@
 """Fuzz beyond the committed seeds: random MJCF models (tests/random_models.py) through the general kernels against the checker,
-rollouts bit for bit.  usage (GPU box): python tools/gpu_fuzz_models.py FIRST COUNT [planar | planar3d]"""
+rollouts bit for bit.  usage (GPU box): python tools/gpu_fuzz_models.py FIRST COUNT [planar | planar3d | spec | planarspec]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "model-based-diffusion_amd"), os.path.join(ROOT, "tests")):
@@ -14,25 +14,31 @@ orc_mod.build()
 orc = orc_mod.Oracle("f32")
 first, count = int(sys.argv[1]), int(sys.argv[2])
 mode = sys.argv[3] if len(sys.argv) > 3 else "3d"
-bad = refused = 0
+bad = refused = touched = 0
 kinds = {}
 for seed in range(first, first + count):
-    if mode == "3d":
-        _, m = stable_random_model(seed, _comp)
+    bits = 0
+    if mode.endswith("spec"):  # a random subset of the specification switches (include/mbd_hip.h mbd_model_flags)
+        bits = int(np.random.default_rng(1000 + seed).integers(1, 64)) * 4
+    if mode in ("3d", "spec"):
+        _, m = stable_random_model(seed, lambda x: _comp(x, spec_flags=bits))
+    elif mode == "planarspec":
+        _, m = stable_random_model(seed, lambda x: _comp(x, env_name="halfcheetah", spec_flags=bits & (4 | 8 | 16 | 32)), planar=True, max_bodies=10)
     else:
         _, m = stable_random_model(seed, lambda x: _comp(x, env_name="halfcheetah", planar=None if mode == "planar" else False),
                                    planar=True, max_bodies=10)
     try:
-        env = RigidBodyEnv("hopper" if mode == "3d" else "halfcheetah", model=m)
+        env = RigidBodyEnv("hopper" if mode in ("3d", "spec") else "halfcheetah", model=m)
     except Exception as e:  # a shape the library refuses (says so)
         refused += 1
         print(seed, "refused:", str(e)[:120])
         continue
     st = env.reset(_capi.prng_key(seed))
-    us = np.clip(np.random.default_rng(seed).normal(size=(21, 25, env.action_size)) * 0.6, -1.3, 1.3).astype(np.float32)
+    us = np.clip(np.random.default_rng(seed).normal(size=(21, 90, env.action_size)) * 0.6, -1.3, 1.3).astype(np.float32)
     got = env.rollout(st, us).cpu().numpy()
     ref = orc.rollout(m.to_struct(), np.asarray(st.pipeline_state, np.float32), us)
+    touched += int(np.abs(np.diff(ref, axis=1)).max() > 0.02)  # (a jump of the per-step reward: an impact)
     if not np.array_equal(got, ref):
         bad += 1
         print(seed, "MISMATCH max|d|", np.abs(got - ref).max(), "links", m.n_links)
-print(f"{mode} seeds {first}..{first + count - 1}: {bad} mismatches, {refused} refused")
+print(f"{mode} seeds {first}..{first + count - 1}: {bad} mismatches, {refused} refused, {touched} with an impact in the horizon")
