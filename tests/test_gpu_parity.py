@@ -189,6 +189,37 @@ def test_random_models_on_the_general_kernels(gpu, orc, seed, levers):
     _one_step(gpu, orc, "hopper", 64, 10, 20, 0.1, 1, False, i=10, env=env)
 
 
+def test_custom_model_with_three_colliders_on_a_link(gpu, orc):
+    """A fused body hands its spheres to its parent's link: three to five colliders on a link outside the humanoids' shape
+    run through the general instantiation of the specification switches (five collider slots, zero flag word = the default
+    specification), bit for bit; more than five are refused by name."""
+    from random_models import random_mjcf, stable_random_model
+    from test_random_models import _comp
+    from mbd_hip.envs.base import RigidBodyEnv
+    found = 0
+    for seed in range(16, 200):
+        _, m = stable_random_model(seed, _comp)
+        F = m.fields
+        most = int(np.bincount(np.asarray(F["col_link"][:int(F["n_col"])]), minlength=m.n_links).max())
+        if most < 3:
+            continue
+        assert most <= 5
+        env = RigidBodyEnv("hopper", model=m)
+        st = env.reset(gpu.prng_key(seed))
+        us = np.clip(np.random.default_rng(seed).normal(size=(21, 90, env.action_size)) * 0.6, -1.3, 1.3).astype(np.float32)
+        got = env.rollout(st, us).cpu().numpy()
+        ref = _oenv(orc, env).rollout(np.asarray(st.pipeline_state, np.float32), us)
+        assert np.array_equal(got, ref), f"seed {seed}: max |d| = {np.abs(got - ref).max()}"
+        found += 1
+        if found == 3:
+            break
+    assert found == 3
+    six = random_mjcf(0, max_bodies=3, kinds=("h1",), probs=(1,)).replace(
+        "</body>", "".join(f'<geom type="sphere" pos="0 {0.02 * k} 0" size="0.03" contype="1" conaffinity="1"/>' for k in range(6)) + "</body>", 1)
+    with pytest.raises(Exception, match="colliders"):
+        RigidBodyEnv("hopper", model=_comp(six))
+
+
 @pytest.mark.parametrize("planar", [None, False])
 @pytest.mark.parametrize("seed", range(8))
 def test_random_planar_models(gpu, orc, seed, planar):
