@@ -69,7 +69,7 @@ def reverse_once(orc: Oracle, env: OracleEnv, state0, i, rng, Ybar_i, sched, N, 
     rng, ks = keys[0], keys[1]
     Y0s = orc.sample(ks, impl, N, H, env.Nu, 0, N, float(sigmas[i]), Ybar_i)  # :104-106
     t1 = time.perf_counter()
-    lp = None
+    lp = xpos = None
     if enable_demo:
         rewss, xpos = env.rollout(state0, Y0s, want_xpos=True)  # :109
         lp = env.logpd(xpos)  # :118
@@ -84,7 +84,7 @@ def reverse_once(orc: Oracle, env: OracleEnv, state0, i, rng, Ybar_i, sched, N, 
         t3 = time.perf_counter()
         for k, v in (("sample", t1 - t0), ("rollout", t2 - t1), ("score", t3 - t2)):
             timers[k] = timers.get(k, 0.0) + v
-    return rng, Ybar_im1, rew_mean, dict(Y0s=Y0s, rewss=rewss, rews=rews, weights=w, lp=lp)
+    return rng, Ybar_im1, rew_mean, dict(Y0s=Y0s, rewss=rewss, rews=rews, weights=w, lp=lp, xpos=xpos)
 
 
 def run_diffusion(orc: Oracle, env: OracleEnv, seed, N, H, Nd, temp, beta0=1e-4, betaT=1e-2, impl=1,

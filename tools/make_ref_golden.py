@@ -84,10 +84,41 @@ def make_jnp():
     return m
 
 
+class _Node:
+    """a pytree node of the stand-in (brax.envs.base.State, brax.base.State / Transform / Motion look-alikes): an attribute bag
+    with flax's .replace; stacked, indexed and measured field by field (what lax.scan / vmap do to pytrees)"""
+    def __init__(self, **kw):
+        self.__dict__.update(kw)
+
+    def replace(self, **kw):
+        d = dict(self.__dict__)
+        d.update(kw)
+        return type(self)(**d)
+
+    def __len__(self):
+        return len(next(v for v in self.__dict__.values() if isinstance(v, (np.ndarray, _Node))))
+
+    def __getitem__(self, k):
+        return type(self)(**{n: (v[k] if isinstance(v, (np.ndarray, _Node)) else v) for n, v in self.__dict__.items()})
+
+
+class BraxEnvState(_Node):
+    """brax.envs.base.State(pipeline_state, obs, reward, done, metrics, info)"""
+    def __init__(self, pipeline_state=None, obs=None, reward=None, done=None, metrics=None, info=None):
+        super().__init__(pipeline_state=pipeline_state, obs=obs, reward=reward, done=done,
+                         metrics={} if metrics is None else metrics, info={} if info is None else info)
+
+
 def _tree_stack(items):
     x = items[0]
     if isinstance(x, tuple):
         return tuple(_tree_stack([it[k] for it in items]) for k in range(len(x)))
+    if isinstance(x, _Node):
+        return type(x)(**{n: _tree_stack([getattr(it, n) for it in items]) for n in x.__dict__})
+    if isinstance(x, dict):
+        return {n: _tree_stack([it[n] for it in items]) for n in x}
+    if x is None:
+        return None
     return _w(np.stack([np.asarray(it) for it in items]))
 
 
@@ -120,7 +151,8 @@ def make_jax(orc, impl):
             outs = [f(*[(a if ax is None else a[k]) for a, ax in zip(args, axes)]) for k in range(n)]
             out = _tree_stack(outs)
             if isinstance(in_axes, tuple) and in_axes == (None, 0) and isinstance(out, tuple):   # vmap(rollout_us)
-                REC["cur"]["rewss"], REC["cur"]["qs"] = np.array(out[0], np.float32), np.array(out[1], np.float32)
+                REC["cur"]["rewss"] = np.array(out[0], np.float32)
+                REC["cur"]["qs"] = np.array(out[1].x.pos if isinstance(out[1], _Node) else out[1], np.float32)
             return out
         return g
     jax.vmap = vmap
@@ -190,7 +222,7 @@ def _fake_mjcf_load(path):
     import xml.etree.ElementTree as ET
     names = []
     if not os.path.exists(str(path)):   # (hopper.py:13 / walker2d.py:14 load their XML from inside the Brax wheel)
-        return _Sys(link_names=names)
+        return _compiled_sys(path, None) if BRAX["orc"] is not None else _Sys(link_names=names)
 
     def walk(e):
         for b in e.findall("body"):
@@ -198,7 +230,78 @@ def _fake_mjcf_load(path):
                 names.append(b.get("name"))
             walk(b)
     walk(ET.parse(str(path)).getroot().find("worldbody"))
-    return _Sys(link_names=names)
+    return _compiled_sys(path, names) if BRAX["orc"] is not None else _Sys(link_names=names)
+
+
+BRAX = {"orc": None, "last_init": None}
+
+
+def _compiled_sys(path, names_from_xml):
+    """what brax.io.mjcf.load returns, as far as the reference's wrappers ask (init_q, sizes, link names, dt): THIS repo's
+    compiled model of the file of that name.  Not the reference's code — the physics underneath it."""
+    from mbd_hip.model import Model
+    name = os.path.splitext(os.path.basename(str(path)))[0]
+    with open(os.path.join(ROOT, "model-based-diffusion_amd", "assets", "compiled", f"{name}.json")) as f:
+        m = Model.from_json(f.read())
+    init_q = m.init_q.copy()
+    if name == "cartpole":       # (the compiled model carries the reset offset of cartpole.py:26 in init_q already)
+        init_q = init_q - np.array([0.0, np.pi], np.float32)
+    names = names_from_xml or list(m.link_names)
+    return _Sys(link_names=names, init_q=_w(init_q), q_size=lambda: m.q_size(), qd_size=lambda: m.qd_size(),
+                act_size=lambda: m.act_size(), dt=float(m.fields["dt"]), _model=m, _ms=m.to_struct(), _name=name,
+                _slot=[names.index(n) for n in m.link_names])
+
+
+def _pstate(sysobj, st):
+    """brax.base.State of a checker state [L, 13]: x.pos = the link frames' origins, x.rot, xd.vel = the origins' velocities
+    (v_com - w x (R com)), xd.ang; listed in the XML's link order (marker bodies this repo's models drop keep zeros); q / qd
+    only where a wrapper's REWARD reads them (cartpole.py:44: hinge angle of the pole, slide velocity of the cart)"""
+    orc, ms, m = BRAX["orc"], sysobj._ms, sysobj._model
+    o = orc.link_positions(ms, st)
+    vel = (st[:, 7:10] - np.cross(st[:, 10:13], st[:, 0:3] - o)).astype(np.float32)
+    n = len(sysobj.link_names)
+    full = lambda a, w: (lambda z: (z.__setitem__(sysobj._slot, a), _w(z))[1])(np.zeros((n, w), np.float32))
+    q, qd = np.zeros(m.q_size(), np.float32), np.zeros(m.qd_size(), np.float32)
+    if sysobj._name == "cartpole":
+        ax = np.asarray(m.fields["slide_axis"][0][0], np.float32)
+        q[0], q[1] = float(o[0] @ ax), float(orc.joint_angles(ms, st)[1][0])
+        qd[0] = float(vel[0] @ ax)
+    return _Node(q=_w(q), qd=_w(qd), x=_Node(pos=full(o, 3), rot=full(st[:, 3:7], 4)),
+                 xd=_Node(vel=full(vel, 3), ang=full(st[:, 10:13], 3)), _st=np.array(st, np.float32))
+
+
+class OrcPipelineEnv:
+    """stands in for brax.envs.base.PipelineEnv under the reference's wrappers: pipeline_init = this repo's forward
+    kinematics, pipeline_step = n_frames substeps of this repo's CPU checker with the action held.  Everything above it —
+    reset, step, rewards, the demo, rollout_us, the planner — is the reference's own code, executed."""
+    def __init__(self, sys=None, backend="generalized", n_frames=1, debug=False, **kw):
+        assert backend == "positional", backend
+        self.sys, self._n_frames, self._backend = sys, int(n_frames), backend
+        assert self._n_frames == int(sys._model.fields["n_frames"]), (sys._name, n_frames)   # (envs/specs.py agrees with the wrapper)
+
+    def pipeline_init(self, q, qd):
+        st = BRAX["orc"].forward(self.sys._ms, np.asarray(q, np.float32), np.asarray(qd, np.float32))
+        BRAX["last_init"] = np.array(st, np.float32)
+        return _pstate(self.sys, st)
+
+    def pipeline_step(self, pipeline_state, action):
+        st = np.asarray(pipeline_state._st, np.float32)
+        act = np.ascontiguousarray(np.asarray(action, np.float32))
+        for _ in range(self._n_frames):
+            st = BRAX["orc"].substep(self.sys._ms, st, act)
+        return _pstate(self.sys, st)
+
+    @property
+    def dt(self):
+        return self.sys.dt * self._n_frames
+
+    @property
+    def action_size(self):
+        return self.sys.act_size()
+
+    @property
+    def observation_size(self):
+        return int(np.asarray(self.reset(BRAX["orc"].prng_key(0)).obs).shape[-1])
 
 
 def _reconstruct_array(fun, args, arr_state, aval_state):
@@ -425,6 +528,39 @@ def env_obs(orc):
     print(f"wrote {path}")
 
 
+def run_brax(orc, env_name, seed, N, H, Nd, temp, demo):
+    """The reference's WHOLE planning run for a Brax-backed env — mbd_planner.run_diffusion, mbd.utils.rollout_us, the env's
+    wrapper (reset, step, reward, the demo's log-density), all executed unchanged — with brax.envs.base.PipelineEnv served by
+    this repo's CPU checker (OrcPipelineEnv: forward kinematics + n_frames substeps) and jax by the numpy stand-in.  What
+    the files pin: how the reference's code COMPOSES a step around the physics (which state a reward reads, humanoidtrack's
+    lagged reward and step counter, n_frames per wrapper, the key chain, the score) — for every wrapper, in situ.  What they
+    do not: Brax's physics (the checker stands in for it)."""
+    BRAX["orc"] = orc
+    base = sys.modules["brax.envs.base"]
+    base.PipelineEnv, base.State = OrcPipelineEnv, BraxEnvState
+    for k in [k for k in sys.modules if k == "mbd" or k.startswith("mbd.")]:   # (their classes were built on the empty stand-in)
+        del sys.modules[k]
+    planner = importlib.import_module("mbd.planners.mbd_planner")
+    REC["steps"], REC["cur"] = [], {}
+    args = planner.Args(seed=seed, env_name=env_name, Nsample=N, Hsample=H, Ndiffuse=Nd, temp_sample=temp, enable_demo=demo,
+                        disable_recommended_params=True, not_render=True)
+    rew_final = planner.run_diffusion(args)
+    out = dict(env=env_name, seed=seed, N=N, H=H, Nd=Nd, temp=np.float32(temp), demo=demo, impl=1, rew_final=np.float32(rew_final),
+               state_init=BRAX["last_init"],
+               made_by="tools/make_ref_golden.py: the reference's mbd_planner.py + utils.py + mbd/envs/%s.py executed under a "
+                       "numpy stand-in for jax, with brax's PipelineEnv served by this repo's CPU checker (NOT outputs of JAX "
+                       "or Brax)" % env_name)
+    for key in ("i", "rng_in", "rng_out", "Ybar_i", "Ybar_im1", "rew_mean", "rewss", "logp0", "weights"):
+        out[key] = np.stack([np.asarray(st[key]) for st in REC["steps"]])
+    out["eps"] = np.stack([np.asarray(st["eps"]) for st in REC["steps"][:1]])
+    if demo:   # the tracked links' positions of the first step (what eval_xref_logpd read), in the wrapper's own order
+        env = importlib.import_module("mbd.envs").get_env(env_name)
+        out["xpos_tracked"] = np.asarray(REC["steps"][0]["qs"])[:, :, np.asarray(env.track_body_idx)]
+    path = os.path.join(ROOT, "tests", "golden", f"ref_run_{env_name}{'_demo' if demo else ''}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(REC['steps'])} steps, rew_final = {float(rew_final):.6f}")
+
+
 def main():
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     os.environ.setdefault("TQDM_DISABLE", "1")
@@ -444,6 +580,10 @@ def main():
     orc_key = lambda seed: orc.split(orc.prng_key(seed), 2, 1)[1]   # rng_reset of mbd_planner.py:79
     env_resets()
     env_obs(orc)
+    for env_name, N, H, Nd, demo in (("humanoidrun", 32, 20, 6, False), ("hopper", 24, 12, 5, False), ("walker2d", 16, 10, 4, False),
+                                     ("humanoidstandup", 16, 12, 4, False), ("cartpole", 32, 20, 5, False),
+                                     ("humanoidtrack", 16, 20, 4, False), ("humanoidtrack", 16, 50, 4, True)):
+        run_brax(orc, env_name, 1, N, H, Nd, 0.1, demo)
 
 
 if __name__ == "__main__":
