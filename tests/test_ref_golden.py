@@ -354,3 +354,82 @@ def test_gpu_whole_runs_match_the_executed_reference(run):
         assert np.abs(rewss - g["rewss"][k]).max() < 1e-5 and np.allclose(w, g["weights"][k], rtol=1e-2, atol=1e-8)
     assert abs(plan.eval(g["Ybar_im1"][-1]) - float(g["rew_final"])) < 1e-5
     plan.close()
+
+
+PI_RUNS = ["hopper_mppi", "hopper_cma-es", "hopper_cem", "humanoidrun_mppi", "humanoidrun_cma-es"]
+
+
+@pytest.mark.parametrize("run", PI_RUNS)
+def test_path_integral_runs_match_the_executed_reference(orc, run):
+    """tests/golden/ref_pi_run_*.npz: the reference's run_path_integral (path_integral.py:55-148) executed whole over the
+    checker-backed PipelineEnv.  Every recorded update_once, teacher-forced (its key, mean and sigma in): key chain exact,
+    the candidates' rewards 1e-5, the new mean 1e-5 (cem: the same elites, so 1e-6), sigma 1e-4 relative, mean reward 1e-5;
+    the reset state and rew_final of the file's last mean."""
+    from conftest import load_model
+    from oracle import planner as op
+    g = np.load(os.path.join(GOLD, f"ref_pi_run_{run}.npz"))
+    name, method = str(g["env"]), str(g["method"])
+    N, H, Nr, temp = int(g["N"]), int(g["H"]), int(g["Nr"]), float(g["temp"])
+    m = load_model(name)
+    env = op.OracleEnv(orc, name, m.to_struct(), init_q=m.init_q)
+    rng, rng_reset = orc.split(orc.prng_key(int(g["seed"])), 2, 1)
+    st0 = env.reset(rng_reset, 1)
+    assert np.array_equal(st0, g["state_init"])
+    assert np.array_equal(orc.split(rng, 2, 1)[0], g["rng_in"][0]) and float(g["sigma_in"][0]) == 1.0   # :144, :131
+    assert list(g["t"]) == list(range(Nr - 1, 0, -1))
+    for k in range(len(g["t"])):
+        keys = orc.split(g["rng_in"][k], 2, 1)
+        assert np.array_equal(keys[0], g["rng_out"][k])
+        Y0s = orc.sample(keys[1], 1, N, H, env.Nu, 0, N, float(g["sigma_in"][k]), g["mu_in"][k])
+        rewss = env.rollout(st0, Y0s)
+        assert np.abs(rewss - g["rewss"][k]).max() < 1e-5
+        mu, sigma, w, rm = orc.pi_update(op.PI_METHODS[method], op.mean_h(orc, np.ascontiguousarray(rewss)), Y0s, g["mu_in"][k],
+                                         float(g["sigma_in"][k]), temp)
+        assert np.allclose(w, g["weights"][k], rtol=1e-2, atol=1e-8)
+        assert np.abs(mu - g["mu_out"][k]).max() < 1e-5, (k, np.abs(mu - g["mu_out"][k]).max())
+        assert abs(float(sigma) - float(g["sigma_out"][k])) <= 1e-4 * float(g["sigma_out"][k])
+        assert abs(float(rm) - float(g["rew_mean"][k])) < 1e-5
+        if k + 1 < len(g["t"]):
+            assert np.array_equal(g["mu_in"][k + 1], g["mu_out"][k]) and g["sigma_in"][k + 1] == g["sigma_out"][k]
+    rew = env.rollout(st0, g["mu_out"][-1][None])
+    assert abs(float(np.mean(rew)) - float(g["rew_final"])) < 1e-5
+    if method == "cma-es":
+        assert float(g["sigma_out"][-1]) < 0.1   # (the spread collapses; the reference floors it at 1e-3)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("run", PI_RUNS)
+def test_gpu_path_integral_runs_match_the_executed_reference(run):
+    """The PRODUCT against the same files: each update_once teacher-forced through the C ABI (mbd_plan_set_sigma, the mean and
+    the key in; mbd_plan_reverse_once; mbd_plan_get_sigma)."""
+    import ctypes as C
+    import torch
+    from mbd_hip import _capi
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.mbd_planner import Plan
+    from mbd_hip.planners.path_integral import UPDATE_METHODS, Args
+    if _capi.device_count() < 1:
+        pytest.fail("GPU tests need a visible MI355X; the product has no CPU fallback")
+    g = np.load(os.path.join(GOLD, f"ref_pi_run_{run}.npz"))
+    name, method = str(g["env"]), str(g["method"])
+    N, H, Nr, temp = int(g["N"]), int(g["H"]), int(g["Nr"]), float(g["temp"])
+    env = get_env(name)
+    plan = Plan(env, Args(seed=int(g["seed"]), env_name=name, Nsample=N, Hsample=H, Nrefine=Nr, temp_sample=temp,
+                          update_method=method, disable_recommended_params=True), update_method=UPDATE_METHODS[method])
+    rng, rng_reset = _capi.prng_split(_capi.prng_key(int(g["seed"])), 2)
+    st = env.reset(rng_reset)
+    assert np.array_equal(np.asarray(st.pipeline_state, np.float32).reshape(g["state_init"].shape), g["state_init"])
+    plan.set_state0(st)
+    d_rm = torch.zeros(1, device="cuda")
+    for k in range(len(g["t"])):
+        plan.set_sigma(float(g["sigma_in"][k]))
+        d_Y = torch.tensor(g["mu_in"][k].reshape(-1), device="cuda")
+        key = (C.c_uint32 * 2)(int(g["rng_in"][k][0]), int(g["rng_in"][k][1]))
+        _capi.check(plan.lib.mbd_plan_reverse_once(plan.h, int(g["t"][k]), key, d_Y.data_ptr(), d_rm.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert [key[0], key[1]] == [int(x) for x in g["rng_out"][k]]
+        assert np.abs(d_Y.cpu().numpy().reshape(g["mu_out"][k].shape) - g["mu_out"][k]).max() < 1e-5, k
+        assert abs(plan.get_sigma() - float(g["sigma_out"][k])) <= 1e-4 * float(g["sigma_out"][k])
+        assert abs(float(d_rm.item()) - float(g["rew_mean"][k])) < 1e-5
+    assert abs(plan.eval(g["mu_out"][-1]) - float(g["rew_final"])) < 1e-5
+    plan.close()

@@ -141,6 +141,17 @@ def make_jax(orc, impl):
                 REC["steps"].append(REC["cur"])
                 return (i2, rng2, Yn), rew
             return wrapped
+        if getattr(f, "__name__", "") == "update_once":     # path_integral.py:111-127: the same, for the baselines' step
+            def wrapped_pi(carry, unused):
+                t, rng, mu, sigma = carry
+                REC["cur"] = {"t": int(t), "rng_in": np.array(rng, np.uint32), "mu_in": np.array(mu, np.float32),
+                              "sigma_in": np.float32(sigma)}
+                (t2, rng2, mu2, sigma2), rew = f(carry, unused)
+                REC["cur"].update(rng_out=np.array(rng2, np.uint32), mu_out=np.array(mu2, np.float32),
+                                  sigma_out=np.float32(sigma2), rew_mean=np.float32(rew))
+                REC["steps"].append(REC["cur"])
+                return (t2, rng2, mu2, sigma2), rew
+            return wrapped_pi
         return f
     jax.jit = jit
 
@@ -150,6 +161,8 @@ def make_jax(orc, impl):
             n = next(len(a) for a, ax in zip(args, axes) if ax is not None)
             outs = [f(*[(a if ax is None else a[k]) for a, ax in zip(args, axes)]) for k in range(n)]
             out = _tree_stack(outs)
+            if isinstance(in_axes, tuple) and in_axes == (None, 0) and not isinstance(out, tuple) and "t" in REC["cur"]:
+                REC["cur"]["rewss"] = np.array(out, np.float32)                                   # vmap(eval_us)
             if isinstance(in_axes, tuple) and in_axes == (None, 0) and isinstance(out, tuple):   # vmap(rollout_us)
                 REC["cur"]["rewss"] = np.array(out[0], np.float32)
                 REC["cur"]["qs"] = np.array(out[1].x.pos if isinstance(out[1], _Node) else out[1], np.float32)
@@ -561,6 +574,30 @@ def run_brax(orc, env_name, seed, N, H, Nd, temp, demo):
     print(f"wrote {path}: {len(REC['steps'])} steps, rew_final = {float(rew_final):.6f}")
 
 
+def run_brax_pi(orc, env_name, method, seed, N, H, Nr, temp):
+    """The same for the baselines: the reference's run_path_integral (path_integral.py:55-148) — its sampling, eval_us, the
+    standardisation without a zero-spread guard, softmax and update rule — executed whole over the checker-backed PipelineEnv."""
+    BRAX["orc"] = orc
+    base = sys.modules["brax.envs.base"]
+    base.PipelineEnv, base.State = OrcPipelineEnv, BraxEnvState
+    for k in [k for k in sys.modules if k == "mbd" or k.startswith("mbd.")]:
+        del sys.modules[k]
+    pi = importlib.import_module("mbd.planners.path_integral")
+    REC["steps"], REC["cur"] = [], {}
+    args = pi.Args(seed=seed, env_name=env_name, Nsample=N, Hsample=H, Nrefine=Nr, temp_sample=temp, update_method=method,
+                   disable_recommended_params=True)
+    rew_final = pi.run_path_integral(args)
+    out = dict(env=env_name, method=method, seed=seed, N=N, H=H, Nr=Nr, temp=np.float32(temp), impl=1,
+               rew_final=np.float32(rew_final), state_init=BRAX["last_init"],
+               made_by="tools/make_ref_golden.py: the reference's path_integral.py + utils.py + mbd/envs/%s.py executed under a "
+                       "numpy stand-in for jax, brax's PipelineEnv served by this repo's CPU checker (NOT outputs of JAX or Brax)" % env_name)
+    for key in ("t", "rng_in", "rng_out", "mu_in", "mu_out", "sigma_in", "sigma_out", "rew_mean", "rewss", "weights"):
+        out[key] = np.stack([np.asarray(st[key]) for st in REC["steps"]])
+    path = os.path.join(ROOT, "tests", "golden", f"ref_pi_run_{env_name}_{method}.npz")
+    np.savez_compressed(path, **out)
+    print(f"wrote {path}: {len(REC['steps'])} steps, rew_final = {float(rew_final):.6f}, sigma {float(out['sigma_out'][-1]):.4g}")
+
+
 def main():
     ref = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
     os.environ.setdefault("TQDM_DISABLE", "1")
@@ -584,6 +621,9 @@ def main():
                                      ("humanoidstandup", 16, 12, 4, False), ("cartpole", 32, 20, 5, False),
                                      ("humanoidtrack", 16, 20, 4, False), ("humanoidtrack", 16, 50, 4, True)):
         run_brax(orc, env_name, 1, N, H, Nd, 0.1, demo)
+    for env_name, method, N, H, Nr in (("hopper", "mppi", 48, 15, 6), ("hopper", "cma-es", 48, 15, 6), ("hopper", "cem", 48, 15, 6),
+                                       ("humanoidrun", "mppi", 32, 10, 4), ("humanoidrun", "cma-es", 32, 10, 4)):
+        run_brax_pi(orc, env_name, method, 2, N, H, Nr, 0.1)
 
 
 if __name__ == "__main__":
