@@ -19,6 +19,7 @@ against closed-form masses, centres of mass and inertias instead (tests/test_mjc
 from __future__ import annotations
 
 import math
+import os
 import xml.etree.ElementTree as ET
 from typing import Dict, List, Optional, Sequence
 
@@ -267,12 +268,52 @@ def is_planar(F) -> bool:
     return int(np.asarray(F["track_link"]).size) == 0
 
 
+def stability_report(model) -> List[str]:
+    """What a custom model asks of an explicit, Jacobi-summed position-based step that it cannot give (found by fuzzing
+    random models, tests/random_models.py; properties of the algorithm, not of this implementation).  Returns one line per
+    finding; empty for every built-in model.
+      * constraint / joint dampers act explicitly: a damper d between two links is stable while
+        dt * d * (lambda_max(I_child^-1) + lambda_max(I_parent^-1)) < 2 (angular) resp. dt * d * (1/m_c + 1/m_p) < 2 —
+        which is why the reference's XMLs pair constraint_ang_damping = 30 with spring_inertia_scale = 1 (unit tensors);
+      * the joint stage SUMS the corrections of all joints of a link: with its share w_link / (w_link + w_other) of each,
+        joint_scale_pos * (sum of shares) must stay below 4/3 — beyond it the pose-difference velocity feeds the overshoot
+        back and the links fly apart even in free fall."""
+    F, L = model.fields, model.n_links
+    dt = float(F["dt"])
+    lam = [float(np.linalg.eigvalsh(np.array([[i[0], i[3], i[4]], [i[3], i[1], i[5]], [i[4], i[5], i[2]]], np.float64)).max())
+           for i in np.asarray(F["inv_inertia"][:L], np.float64)]
+    w = np.asarray(F["inv_mass"][:L], np.float64)
+    out, load = [], np.zeros(L)
+    for l in range(L):
+        p = int(F["parent"][l])
+        if int(F["n_rot"][l]) < 0:
+            continue
+        lp, wp = (lam[p], w[p]) if p >= 0 else (0.0, 0.0)
+        d_ang = float(F["ang_damp"][l]) + float(np.max(np.asarray(F["rot_damp"][l])[:max(int(F["n_rot"][l]), 0)], initial=0.0))
+        if dt * d_ang * (lam[l] + lp) >= 2.0:
+            out.append(f"link {model.link_names[l]!r}: angular damping {d_ang:g} is explicit-unstable at dt {dt:g} "
+                       f"(dt d (1/I_c + 1/I_p) = {dt * d_ang * (lam[l] + lp):.3g} >= 2); lower it or use spring_inertia_scale = 1")
+        d_vel = float(F["vel_damp"][l])
+        if dt * d_vel * (w[l] + wp) >= 2.0:
+            out.append(f"link {model.link_names[l]!r}: constraint_vel_damping {d_vel:g} is explicit-unstable at dt {dt:g} "
+                       f"(dt d (1/m_c + 1/m_p) = {dt * d_vel * (w[l] + wp):.3g} >= 2)")
+        load[l] += w[l] / (w[l] + wp)
+        if p >= 0:
+            load[p] += wp / (w[l] + wp)
+    jsp = float(F["joint_scale_pos"])
+    if L and jsp * float(load.max()) >= 4.0 / 3.0:
+        k = int(load.argmax())
+        out.append(f"link {model.link_names[k]!r}: joint_scale_pos {jsp:g} x {load[k]:.2f} (its share of its joints' summed "
+                   f"corrections) = {jsp * load[k]:.2f} >= 4/3: the joint stage overshoots; lower joint_scale_pos to <= {1.2 / load[k]:.2f}")
+    return out
+
+
 def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Optional[str] = None,
          track_names: Sequence[str] = (), reset_noise: float = 0.0,
          reward_params: Sequence[float] = (), dt_override: Optional[float] = None,
          init_q_offset: Sequence[float] = (), gear_override: Sequence[float] = (),
          passive_joint_forces: bool = True, reset_quat_raw: bool = False, planar: Optional[bool] = None,
-         spec_flags: int = 0) -> Model:
+         spec_flags: int = 0, warn_unstable: bool = True) -> Model:
     """Compile an MJCF file. ``n_frames`` is the env's physics substeps per control step
     (humanoidrun.py:17 -> 7, humanoidtrack.py:46 -> 5, hopper.py:18 -> 20).
 
@@ -288,7 +329,8 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
       spec_flags            the CODE-level guesses as flag bits (model.SPEC_FLAGS / model.spec_bits: contact_avg,
                             contact6_jacobi, friction_vel_bound, restitution_min, euler_extrinsic, gyroscopic;
                             include/mbd_hip.h mbd_model_flags): checker and kernels honour them alike.
-    Reward-side switches live in reward_params (ant: [5] = terminate_when_unhealthy)."""
+    Reward-side switches live in reward_params (ant: [5] = terminate_when_unhealthy).
+    warn_unstable: emit ``stability_report``'s findings as warnings (custom models; the built-in ones have none)."""
     root = ET.parse(path).getroot()
     comp = root.find("compiler")
     angle_scale = 1.0 if (comp is not None and comp.get("angle", "degree") == "radian") else math.pi / 180
@@ -561,4 +603,8 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
     model = Model(F, names, act_names, env_name)
     model.masses = np.array([ent["mass"] for ent in links])      # diagnostics / tests only
     model.inertias = np.stack([ent["inertia"] for ent in links])
+    if warn_unstable:
+        import warnings
+        for line in stability_report(model):
+            warnings.warn(f"{os.path.basename(path)}: {line}", stacklevel=2)
     return model

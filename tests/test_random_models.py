@@ -20,7 +20,7 @@ def _comp(xml, **kw):
     with tempfile.NamedTemporaryFile("w", suffix=".xml", delete=False) as f:
         f.write(xml)
     try:
-        args = dict(env_name="hopper", n_frames=3, reset_noise=0.02, reward_params=(1.0, 0.5))
+        args = dict(env_name="hopper", n_frames=3, reset_noise=0.02, reward_params=(1.0, 0.5), warn_unstable=False)
         args.update(kw)
         return mjcf.load(f.name, **args)
     finally:
@@ -104,3 +104,30 @@ def test_jacobi_load_predicts_the_free_fall_instability(orc):
     load, bad = spread(0.7)
     _, good = spread(round(0.9 / load, 3))
     assert load * 0.7 > 4.0 / 3.0 and (not np.isfinite(bad) or bad > 10.0) and good < 1e-3, (load, bad, good)
+
+
+def test_stability_report_of_the_compiler(orc):
+    """mbd_hip.mjcf.stability_report: silent for every built-in model; names the custom models this suite knows to be
+    outside the stable range — CRAB (constraint_ang_damping 30 on true, thin-capsule tensors: a bounded 480 rad/s limit
+    cycle, kept as a violent parity case) and the light-root star of test_jacobi_load_predicts_the_free_fall_instability —
+    and stays silent for what the generator sizes."""
+    import warnings
+    from conftest import load_model
+    from custom_models import CRAB
+    from mbd_hip import mjcf
+    from mbd_hip.envs import specs
+    for name in specs.SPECS:
+        assert mjcf.stability_report(load_model(name)) == [], name
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        crab = _comp(CRAB, warn_unstable=True)
+    assert rec and any("explicit-unstable" in str(w.message) for w in rec)
+    assert any("angular damping" in line for line in mjcf.stability_report(crab))
+    xml = random_mjcf(3, max_bodies=5, kinds=("h1",), probs=(1,), springs=False, sis=(1.0,))
+    xml = xml.replace('size="0.085', 'size="0.04').replace('size="0.09', 'size="0.04')
+    star = _comp(xml.replace('name="joint_scale_pos" data="', 'name="joint_scale_pos" data="0.7" x="') if "joint_scale_pos" in xml
+                 else xml.replace("</custom>", '<numeric name="joint_scale_pos" data="0.7"/></custom>'), warn_unstable=False)
+    assert any("joint_scale_pos" in line for line in mjcf.stability_report(star)), mjcf.stability_report(star)
+    for seed in range(12):
+        _, m = stable_random_model(seed, lambda x: _comp(x, warn_unstable=False))
+        assert not [l for l in mjcf.stability_report(m) if "joint_scale_pos" in l], seed
