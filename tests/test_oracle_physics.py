@@ -30,6 +30,7 @@ def _compile(xml, **kw):
     from mbd_hip import mjcf
     with tempfile.NamedTemporaryFile("w", suffix=".xml", delete=False) as f:
         f.write(xml)
+    kw.setdefault("warn_unstable", False)   # (some test models are violent on purpose; tests/test_random_models.py covers the report)
     try:
         return mjcf.load(f.name, **kw)
     finally:
