@@ -19,6 +19,10 @@
  * It is the SPECIFICATION the HIP kernels are tested against (teacher-forced, per diffusion step);
  * it is not bit-compatible with Brax and no claim of that is made.  tools/dump_golden.py produces
  * real Brax vectors when run under a jax+brax install; tests consume them if present.
+ * What IS pinned to the reference's code (round 4): everything AROUND the physics — the wrappers' reward expressions, which
+ * state each reads, resets, humanoidtrack's lag and step counter, n_frames per wrapper, rollout_us — by executing the
+ * reference's wrappers and planner with THIS file under brax's PipelineEnv (tools/make_ref_golden.py run_brax,
+ * tests/golden/ref_run_*.npz, tests/test_ref_golden.py).
  *
  * NUMERICAL CONTRACT: all arithmetic goes through oracle/spec_math.h (explicit fma order, exact div /
  * sqrt, polynomial atan2) and the per-link code is written in the same masked, lane-uniform form the
