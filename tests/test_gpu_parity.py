@@ -1323,6 +1323,48 @@ def test_sweep_equals_the_plans_run_alone(gpu, name, N, H, Nd, demo, pk2, monkey
         assert np.float32(r) == np.float32(r_seq)
 
 
+@pytest.mark.parametrize("name,bits,um", [("ant", 8 | 128, 0), ("hopper", 4 | 8 | 16 | 32, 0), ("crab", 4 | 64, 0), ("ant", 4 | 16, 2),
+                                          ("random3col", 0, 0)])
+def test_sweeps_on_the_general_instantiations_equal_the_plans_run_alone(gpu, name, bits, um):
+    """Sweeps of models that run on the general instantiation of the specification switches — switched built-in models
+    (3-D and planar), a custom model, a path-integral sweep, and a random model with three colliders on a link (zero flag
+    word) — against the same plans run one by one: mu_0ts, mean rewards, final rewards, bit for bit."""
+    from mbd_hip.planners.mbd_planner import Args, Plan, Sweep
+    from mbd_hip.planners import path_integral
+    if name == "random3col":
+        from random_models import stable_random_model
+        from test_random_models import _comp
+        from mbd_hip.envs.base import RigidBodyEnv
+        for seed in range(16, 400):
+            _, m = stable_random_model(seed, _comp)
+            F = m.fields
+            if int(np.bincount(np.asarray(F["col_link"][:int(F["n_col"])]), minlength=m.n_links).max()) >= 3:
+                break
+        env, env_name = RigidBodyEnv("hopper", model=m), "hopper"
+    else:
+        env = _spec_env(name, bits)
+        env_name = {"crab": "hopper"}.get(name, name)
+    P, N, H, Nd = 3, 48, 12, 5
+    if um == 0:
+        args = Args(env_name=env_name, Nsample=N, Hsample=H, Ndiffuse=Nd, temp_sample=0.1, disable_recommended_params=True, not_render=True)
+    else:
+        args = path_integral.Args(env_name=env_name, Nsample=N, Hsample=H, Nrefine=Nd, temp_sample=0.1, disable_recommended_params=True)
+    keys = np.array([gpu.prng_key(10 + k) for k in range(P)], np.uint32)
+    states = [env.reset(gpu.prng_key(k)) for k in range(P)]
+    sw = Sweep(env, args, P, update_method=um)
+    for k in range(P):
+        sw.set_state0(k, states[k])
+    mu, rm, rf, _ = sw.run(keys)
+    sw.close()
+    for k in range(P):
+        p = Plan(env, args, update_method=um)
+        p.set_state0(states[k])
+        mu1, rm1, rf1, _ = p.run(keys[k])
+        p.close()
+        assert np.array_equal(mu[k], mu1) and np.array_equal(rm[k], rm1) and np.float32(rf[k]) == np.float32(rf1), (name, k)
+    assert not np.array_equal(mu[0], mu[1])
+
+
 def test_temperature_sweep_equals_the_plans_run_alone(gpu):
     """run_mbd.py:42-64: eight temperatures at seed 0 — one sweep whose plans differ in temp_sample only."""
     from mbd_hip.planners.mbd_planner import Args, run_diffusion
