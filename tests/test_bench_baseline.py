@@ -2,7 +2,6 @@
 reference) and falls back to the port.  Neither jax nor brax exists in this image, so the reference branch is
 exercised with stub modules that have the reference's call surface (mbd.planners.mbd_planner.Args / run_diffusion)."""
 import importlib
-import os
 import sys
 import textwrap
 

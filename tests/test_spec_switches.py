@@ -3,7 +3,6 @@ guesses about Brax's positional pipeline as flag bits of the model, honoured by 
 (tests/test_gpu_parity.py) alike.  Default 0 is the specification of rounds 1-3 (the committed self_* goldens still hold
 it bit for bit); every bit selects a named alternative whose effect is pinned here to what it is supposed to be, so that
 tools/compare_golden.py --search can tell the alternatives apart when a real golden arrives."""
-import math
 
 import numpy as np
 import pytest

@@ -4,7 +4,7 @@ import sys, os
 ROOT="/root/repo"
 for p in (ROOT, os.path.join(ROOT, "model-based-diffusion_amd"), os.path.join(ROOT, "tests")):
     sys.path.insert(0, p)
-import numpy as np, types
+import numpy as np
 import test_gpu_parity as T
 from mbd_hip import _capi
 from oracle import oracle as orc_mod

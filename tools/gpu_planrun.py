@@ -2,7 +2,6 @@
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "model-based-diffusion_amd"))
-import numpy as np
 from mbd_hip import _capi
 from mbd_hip.envs import get_env
 from mbd_hip.planners.mbd_planner import Args, Plan
