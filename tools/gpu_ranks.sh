@@ -17,6 +17,7 @@ print('phase_ms', {k:r(v) for k,v in (d.get('phase_ms') or {}).items()})
 print('other_collective', {k:r(v) for k,v in d.get('other_collective',{}).items() if k!='note'})
 print('other_scaling', {k:r(v) for k,v in d.get('other_scaling',{}).items()})
 print('per_rank', [r(x) for x in d.get('per_rank_plan_steps_per_sec',[])])
+x=(d.get('extras') or {}).get('sweep8_replicas'); print('extras.sweep8_replicas', None if x is None else {k:r(v) for k,v in x.items() if k in ('plan_steps_per_sec','ranks_ok')})
 fr=d['final_reward']; print('final_reward equals_one_gpu_bitwise', fr.get('equals_one_gpu_bitwise'), 'over', fr.get('sharded_over', fr.get('replicated_over')), 'mean', r(fr.get('mean')))
 "
   tail -3 gpurun_out/ranks_${c}_err.log | cut -c1-300
