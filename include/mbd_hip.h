@@ -78,17 +78,19 @@ enum mbd_model_flags {
                                   plane over a rollout.  Set by mbd_hip/mjcf.py when the model qualifies (planar=False
                                   keeps the 3-D path); a specification of its own for these models. */
   /* ---- SPECIFICATION SWITCHES: the places where this engine had to guess at CODE level what Brax's positional
-   * pipeline does.  Default 0 = the specification every round so far ran; each bit selects the named
+   * pipeline does.  Default 0 = the specification the tuned kernels compile in; each bit selects the named
    * alternative, in the checker and in the kernels alike (bit-exact against each other either way), so that a golden
    * vector of the real reference flips a flag instead of forcing a rewrite (tools/compare_golden.py --search tries every
    * combination).  Models with any of these bits run the general `spec` kernel instantiations (not the tuned ones). */
-  MBD_FLAG_CONTACT_AVG = 4,        /* several ACTIVE contacts on one link: the link's position correction (stage 4) — and,
-                                      with CONTACT6_JACOBI, its velocity change (stage 6) — is the AVERAGE over them
-                                      (sum * 1/n, n >= 2) instead of the sum; single contacts are untouched               */
-  MBD_FLAG_CONTACT6_JACOBI = 8,    /* stage (6), collisions.resolve_velocity: every contact of a link computes its impulse
-                                      from the SAME velocities (those stage (5) left) and the changes are added in
-                                      collider order — Brax vmaps its contacts — instead of one after the other, each
-                                      seeing what the previous left (Gauss-Seidel per link, the default)                  */
+  MBD_FLAG_CONTACT_AVG = 4,        /* several ACTIVE contacts on one link: the link's position correction (stage 4) and —
+                                      unless CONTACT6_GAUSS_SEIDEL — its velocity change (stage 6) are the AVERAGE over
+                                      them (sum * 1/n, n >= 2) instead of the sum; single contacts are untouched          */
+  MBD_FLAG_CONTACT6_GAUSS_SEIDEL = 8, /* stage (6), collisions.resolve_velocity.  DEFAULT (bit clear, since round 5): every
+                                      contact of a link computes its impulse from the SAME velocities (those stage (5)
+                                      left) and the changes are added in collider order (Jacobi) — the only form Brax's code
+                                      structure allows: it vmaps its contacts and segment-sums their changes per link.
+                                      Bit set: one contact after the other, each seeing what the link's previous contacts
+                                      left (Gauss-Seidel per link — the default of rounds 1-4, kept as the alternative)    */
   MBD_FLAG_FRICTION_VEL_BOUND = 16, /* stage (6) dynamic friction: |dv_t| = min(mu lambda_n / h, |v_t|) (Mueller et al.
                                       2020, eq. 30, literally: the bound is a velocity) instead of
                                       min(mu lambda_n / h * w_t, |v_t|) (the bound is an impulse)                         */

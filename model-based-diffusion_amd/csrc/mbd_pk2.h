@@ -493,7 +493,8 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
         const f2 s = copysign2(splat(two_inv_dt), dq.w);
         w = v3x2{dq.x * s, dq.y * s, dq.z * s};
       }
-      // ---- (6) collisions.resolve_velocity --------------------------------------------------------------
+      // ---- (6) collisions.resolve_velocity (Jacobi per link: every contact sees the velocities stage (5) left) ----
+      const v3x2 v6 = v, w6 = w;
 #pragma unroll
       for (int j = 0; j < MAXCOL; ++j) {
         // (SKIP6 of mbd_kernels.h: ant's second collider — the ankle end of a lower leg — rarely touches; the slot's whole
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
           if (j > 0 && __builtin_expect(__builtin_amdgcn_ballot_w64(con_act[j].x || con_act[j].y) == 0ull, 1)) continue;
         }
         const v3x2 rc = sub2(con_pos[j], p);
-        const v3x2 vpt = add2(v, cross2(w, rc));
+        const v3x2 vpt = add2(v6, cross2(w6, rc));
         f2 vn_prev = splat(0.0f);
         if (elast != 0.0f) vn_prev = add2(v_old, cross2(w_old, rc)).z;
         const f2 vn = vpt.z;

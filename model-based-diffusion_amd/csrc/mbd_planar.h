@@ -73,7 +73,7 @@ __device__ __forceinline__ void pl_qupdate(float& w, float& y, float dth) {
 // twice over NFR / 2 substeps in line instead of NFR / 4 times over four plus a remainder loop: every iteration saved is
 // a taken branch (hopper, n_frames = 20: 7 -> 2 per control step, +2.7 % at N = 512; the in-line body stays under
 // ~30 KB — the humanoid's seven substeps in line, 39 KB, lost 1.9 %).
-// SPEC: the model's specification switches that exist in the plane (mbd_model_flags: contact_avg, contact6_jacobi,
+// SPEC: the model's specification switches that exist in the plane (mbd_model_flags: contact_avg, contact6_gauss_seidel,
 // friction_vel_bound, restitution_min — DESIGN.md §9) are read at run time and honoured as the checker's planar
 // restatement states them; one general instantiation is built with it (models carrying such a bit run there), every other one
 // compiles the default specification in.
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   const float rp0 = M->reward_params[0], rp1 = M->reward_params[1];
   const float dt_ctrl = M->dt * (float)nfr;
   const int spec = SPEC ? (M->flags & MBD_SPEC_FLAGS) : 0;  // (wave-uniform; 0 elsewhere: the tests below fold away)
-  const bool sp_avg = (spec & MBD_FLAG_CONTACT_AVG) != 0, sp_jac = (spec & MBD_FLAG_CONTACT6_JACOBI) != 0;
+  const bool sp_avg = (spec & MBD_FLAG_CONTACT_AVG) != 0, sp_gs = (spec & MBD_FLAG_CONTACT6_GAUSS_SEIDEL) != 0;
   const bool sp_fvel = (spec & MBD_FLAG_FRICTION_VEL_BOUND) != 0, sp_rmin = (spec & MBD_FLAG_RESTITUTION_MIN) != 0;
 
   // ---- exchange -----------------------------------------------------------------------------------------
@@ -493,13 +493,13 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         const float dqy = ffma(qy, qwp, -(qw * qyp));
         om = dqy * __builtin_copysignf(two_inv_dt, dqw);
       }
-      // ---- (6) collisions.resolve_velocity (sequential per link) ---------------------------------------------
+      // ---- (6) collisions.resolve_velocity (Jacobi per link) ---------------------------------------------------
       if constexpr (MAXCOL > 0) {
-        const float vx6 = vx, vz6 = vz, om6 = om;  // (SPEC, contact6_jacobi: what every contact of the link sees)
+        const float vx6 = vx, vz6 = vz, om6 = om;  // what every contact of the link sees (SPEC, contact6_gauss_seidel: the running values)
 #pragma unroll
         for (int j = 0; j < MAXCOL; ++j) {
           const float rcx = cposx[j] - px, rcz = cposz[j] - pz;
-          const float svx = (SPEC && sp_jac) ? vx6 : vx, svz = (SPEC && sp_jac) ? vz6 : vz, som = (SPEC && sp_jac) ? om6 : om;
+          const float svx = (SPEC && sp_gs) ? vx : vx6, svz = (SPEC && sp_gs) ? vz : vz6, som = (SPEC && sp_gs) ? om : om6;
           const float vptx = ffma(som, rcz, svx), vptz = ffma(-som, rcx, svz);
           float vn_prev = 0.0f;
           if (FL >= 0 ? (FL & 4) != 0 : elast != 0.0f) vn_prev = ffma(-om_old, rcx, vz_old);  // (wave-uniform; with e = 0 the term is exactly 0)
@@ -519,7 +519,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
           vx = cact[j] ? nvx : vx; vz = cact[j] ? nvz : vz; om = cact[j] ? nom : om;
         }
         if constexpr (SPEC) {
-          if (sp_jac && sp_avg) {  // the average of the link's velocity changes: v6 + (v - v6) / n
+          if (!sp_gs && sp_avg) {  // the average of the link's velocity changes: v6 + (v - v6) / n
             int n_act = 0;
 #pragma unroll
             for (int j = 0; j < MAXCOL; ++j) n_act += cact[j] ? 1 : 0;

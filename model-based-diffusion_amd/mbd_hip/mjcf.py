@@ -327,7 +327,7 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
       planar                None: set MBD_FLAG_PLANAR when the model qualifies (see ``is_planar``); False: keep
                             the general 3-D arithmetic for a planar model.
       spec_flags            the CODE-level guesses as flag bits (model.SPEC_FLAGS / model.spec_bits: contact_avg,
-                            contact6_jacobi, friction_vel_bound, restitution_min, euler_extrinsic, gyroscopic;
+                            contact6_gauss_seidel, friction_vel_bound, restitution_min, euler_extrinsic, gyroscopic;
                             include/mbd_hip.h mbd_model_flags): checker and kernels honour them alike.
     Reward-side switches live in reward_params (ant: [5] = terminate_when_unhealthy).
     warn_unstable: emit ``stability_report``'s findings as warnings (custom models; the built-in ones have none)."""

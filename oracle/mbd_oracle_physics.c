@@ -569,13 +569,17 @@ static void substep(const mbd_model_t* m, xf_t* x, mo_t* xd, const real* tau_rot
   dump_stage(4, L, x, xd); /* (5) */
   /* ---- (6) collisions.resolve_velocity: restitution + dynamic friction at active contacts */
   for (int l = 0; l < L; ++l) inert_refresh(&in[l], x[l].r);
-  const int jacobi6 = (m->flags & MBD_FLAG_CONTACT6_JACOBI) != 0;
-  mo_t xd6[MBD_MAX_LINKS]; /* the velocities stage (5) left: what every contact sees under MBD_FLAG_CONTACT6_JACOBI */
+  /* Jacobi per link (default since round 5): every contact of a link computes its impulse from the velocities stage (5)
+   * left and the changes are added in collider order — what a vmap over contacts followed by a per-link segment sum (Brax's
+   * code structure: hopper.py:18,40 and envs/__init__.py:30-31 reach it through PipelineEnv) computes.
+   * MBD_FLAG_CONTACT6_GAUSS_SEIDEL keeps the sequential form of rounds 1-4. */
+  const int jacobi6 = (m->flags & MBD_FLAG_CONTACT6_GAUSS_SEIDEL) == 0;
+  mo_t xd6[MBD_MAX_LINKS]; /* the velocities stage (5) left: what every contact of a link sees (Jacobi) */
   for (int l = 0; l < L; ++l) xd6[l] = xd[l];
   for (int k = 0; k < m->n_col; ++k) {
     if (!con[k].active) continue;
     const int l = m->col_link[k];
-    const mo_t* see = jacobi6 ? &xd6[l] : &xd[l]; /* (default: what the link's previous contacts left — Gauss-Seidel) */
+    const mo_t* see = jacobi6 ? &xd6[l] : &xd[l]; /* (Gauss-Seidel: what the link's previous contacts left) */
     real rc[3], t[3], vpt[3], vprev[3];
     sp_sub3(con[k].pos, x[l].p, rc);
     sp_cross3(see->w, rc, t); sp_add3(see->v, t, vpt);

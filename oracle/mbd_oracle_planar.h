@@ -300,9 +300,9 @@ static void substep_planar(const mbd_model_t* m, pxf_t* x, pmo_t* xd, const real
     xd[l].om = dqy * sp_copysign(two_inv_dt, dqw);
   }
   PL_DUMP(4);
-  /* ---- (6) collisions.resolve_velocity (sequential per link; MBD_FLAG_CONTACT6_JACOBI: every contact of a link from the
-   * velocities stage (5) left, the changes added in collider order) ------------------------------------------------- */
-  const int jacobi6 = (m->flags & MBD_FLAG_CONTACT6_JACOBI) != 0;
+  /* ---- (6) collisions.resolve_velocity (Jacobi per link: every contact of a link from the velocities stage (5) left,
+   * the changes added in collider order; MBD_FLAG_CONTACT6_GAUSS_SEIDEL: one after the other, the form of rounds 1-4) - */
+  const int jacobi6 = (m->flags & MBD_FLAG_CONTACT6_GAUSS_SEIDEL) == 0;
   pmo_t xd6[MBD_MAX_LINKS];
   for (int l = 0; l < L; ++l) xd6[l] = xd[l];
   for (int k = 0; k < m->n_col; ++k) {

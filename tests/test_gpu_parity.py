@@ -1726,7 +1726,7 @@ def _spec_env(name, bits, planar=None):
     ("crab", None, 4), ("crab", None, 8), ("crab", None, 16), ("crab", None, 32), ("crab", None, 64), ("crab", None, 128),
     ("crab", None, 252)])
 def test_specification_switches_bitexact(gpu, orc, name, planar, bits):
-    """Every specification switch (include/mbd_hip.h mbd_model_flags: contact_avg 4, contact6_jacobi 8, friction_vel_bound
+    """Every specification switch (include/mbd_hip.h mbd_model_flags: contact_avg 4, contact6_gauss_seidel 8, friction_vel_bound
     16, restitution_min 32, euler_extrinsic 64, gyroscopic 128), alone and combined, on every inertia class of the 3-D SPEC
     instantiations (isotropic: the humanoids, ant; axisymmetric: hopper / walker2d / tripod compiled 3-D; full tensors:
     the crab) and on the planar SPEC instantiation: reset (forward kinematics under euler_extrinsic), rollouts and one

@@ -94,10 +94,10 @@ SLED = """<mujoco><compiler angle="degree" inertiafromgeom="true"/>
 </body></worldbody></mujoco>"""
 
 
-def _slide(orc, mu, deg):
+def _slide(orc, mu, deg, bits=0):
     """a four-runner sled (cannot roll) under gravity tilted by `deg`: (creep speed after settling, acceleration)"""
     th, g, dt = math.radians(deg), 9.81, 0.002
-    m = _compile(SLED.format(gx=g * math.sin(th), gz=-g * math.cos(th), mu=mu))
+    m = _compile(SLED.format(gx=g * math.sin(th), gz=-g * math.cos(th), mu=mu)).with_spec(bits)
     assert m.fields["n_col"] == 4 and abs(float(m.fields["friction"]) - mu) < 1e-6
     ms = m.to_struct()
     st = orc.forward(ms, m.init_q, np.zeros(6, np.float32))
@@ -116,11 +116,16 @@ def test_friction_cone_on_an_incline(orc, mu):
     DESIGN.md §9's unswitched guesses) against Coulomb on an incline: the sled holds below the cone (tan theta <= 0.8
     mu), slides above it, and well above it accelerates at g (sin theta - mu_eff cos theta) with mu <= mu_eff <= mu (1
     + 0.2 mu): the positional scheme's friction is a little stronger than Coulomb's (lambda_n includes the standing
-    penetration being corrected), never weaker, and nowhere near a factor off."""
+    penetration being corrected), never weaker, and nowhere near a factor off.
+    (Round 5: stage (6) is Jacobi per link and the four runners' velocity changes are SUMMED — each cancels the whole
+    normal velocity of the one rigid link, so the held sled jitters at up to 8 mm/s instead of Gauss-Seidel's 2 mm/s;
+    the averaged form — MBD_FLAG_CONTACT_AVG, the other half of that guess — holds it at 2 mm/s.  It holds either way.)"""
     g = 9.81
     for tan_over_mu in (0.35, 0.8):
         creep, acc = _slide(orc, mu, math.degrees(math.atan(tan_over_mu * mu)))
-        assert creep < 5e-3 and abs(acc) < 1e-2, (mu, tan_over_mu, creep, acc)
+        assert creep < 1e-2 and abs(acc) < 1e-2, (mu, tan_over_mu, creep, acc)
+        creep, acc = _slide(orc, mu, math.degrees(math.atan(tan_over_mu * mu)), bits=4)
+        assert creep < 3e-3 and abs(acc) < 1e-3, (mu, tan_over_mu, creep, acc)
     for tan_over_mu in (1.7, 2.4, 3.5):
         deg = math.degrees(math.atan(tan_over_mu * mu))
         _, acc = _slide(orc, mu, deg)

@@ -19,6 +19,33 @@ XREF = os.path.join(ROOT, "model-based-diffusion_amd", "assets", "compiled", "ca
 FILES = ["config1", "demo", "demo256"]
 
 
+def score_tol(rewss, temp, sigma, demo=False):
+    """How far float32 round-off may move a step's softmax weights and weighted mean between two correct evaluations of
+    mbd_planner.py:110-128 — the stated bound behind the tolerances below, from the step's own data.
+    A candidate's reward r is the mean of H float32 terms, each rounded once per evaluation (numpy evaluates the reference's
+    reward expression, C the checker's; cos / abs / clip results differ by an ulp of the TERM) and summed in another order:
+    the two means differ by dr <= 4 * 2^-24 * max|term|.  logp0 = (r - mean) / std / temp then moves by dr / (std * temp)
+    (the mean's own error is common to all candidates and leaves the softmax; std's relative error, ~1e-6, scales every
+    logp0 alike: 2e-5 of a weight for |logp0| <= 20); a weight ~ exp(logp0) moves by that RELATIVE amount; the weighted mean
+    sum_n w_n Y_n by at most rtol_w times the weighted mean deviation of the candidates, ~ sigma_i.  Measured against it
+    (tools/make_ref_golden.py's files): humanoidstandup's first step 1.11e-3 observed / 2.3e-3 allowed, cartpole 2.7e-4 /
+    3.1e-4, everything else 1e-5 ... 7e-5 / 3e-5 ... 1e-4 — round 4 gave EVERY file rtol 1e-2 for humanoidstandup's sake
+    (rewards 0.5 +- 3e-4 at temp 0.1).  Demo steps add 1e-3: the demo's log-density (a sum of 250 squared distances, up to
+    1e2, so 1e-5 absolute) enters logp0 through / std / temp once more (:121,125)."""
+    rewss = np.asarray(rewss, np.float64)
+    rews = rewss.mean(axis=-1)
+    std = float(rews.std())
+    std = 1.0 if std < 1e-4 else std                      # (:112)
+    raw = 4.0 * 2.0 ** -24 * float(np.abs(rewss).max()) / (std * temp)
+    return 2e-5 + raw + (1e-3 if demo else 0.0), max(1e-5, 2e-6 + float(sigma) * raw)
+
+
+def sigma_of(i, Nd, beta0=1e-4, betaT=1e-2):
+    """sigmas[i] of mbd_planner.py:84-87"""
+    ab = np.cumprod(1.0 - np.linspace(beta0, betaT, Nd))
+    return float(np.sqrt(1.0 - ab[i]))
+
+
 def _env(orc, g):
     from oracle import planner as op
     return op.OracleEnv(orc, "car2d", xref=np.load(XREF), rew_xref=float(g["rew_xref"]))
@@ -290,7 +317,8 @@ def test_whole_runs_of_the_brax_backed_wrappers_match_the_executed_reference(orc
     step, this repo's restatement of the SAME composition (oracle/planner.py over the C env step: reward expressions, which
     state each reads, humanoidtrack's lag and counter, n_frames, the demo blend) must give: the reset state exactly, the key
     chain exactly, the candidates' rewards to 1e-5 (numpy evaluates the reference's reward expressions; the physics below is
-    the same code), weights to 1e-2 relative, Ybar_{i-1} to 1e-5, the mean reward and rew_final to 1e-5."""
+    the same code), weights and Ybar_{i-1} to score_tol's round-off bound (3e-5 ... 2e-3 relative; 1e-5 except humanoidstandup), the mean
+    reward and rew_final to 1e-5."""
     from oracle import planner as op
     g = np.load(os.path.join(GOLD, f"ref_run_{run}.npz"))
     N, H, Nd, temp, demo = int(g["N"]), int(g["H"]), int(g["Nd"]), float(g["temp"]), bool(g["demo"])
@@ -311,9 +339,9 @@ def test_whole_runs_of_the_brax_backed_wrappers_match_the_executed_reference(orc
             if demo:   # the tracked links, in the wrapper's order (humanoidtrack.py:26-28), as eval_xref_logpd read them
                 assert np.abs(det["xpos"] - g["xpos_tracked"]).max() < 1e-6
         assert np.abs(det["rewss"] - g["rewss"][k]).max() < 1e-5, (k, np.abs(det["rewss"] - g["rewss"][k]).max())
-        # (weights: 1e-7 of reward round-off over a reward spread of 1e-3 — humanoidstandup — and temp 0.1 is 1e-3 of logp0)
-        assert np.allclose(det["weights"], g["weights"][k], rtol=1e-2, atol=1e-8), k
-        assert np.abs(Y - g["Ybar_im1"][k]).max() < 1e-5, k
+        rtol_w, tol_Y = score_tol(g["rewss"][k], temp, sigma_of(int(g["i"][k]), Nd), demo)   # (the bound: score_tol's docstring)
+        assert np.allclose(det["weights"], g["weights"][k], rtol=rtol_w, atol=1e-8), (k, rtol_w)
+        assert np.abs(Y - g["Ybar_im1"][k]).max() < tol_Y, (k, tol_Y)
         assert abs(float(rm) - float(g["rew_mean"][k])) < 1e-5
     rew = env.rollout(st0, g["Ybar_im1"][-1][None])
     assert abs(float(np.mean(rew)) - float(g["rew_final"])) < 1e-5
@@ -324,7 +352,7 @@ def test_whole_runs_of_the_brax_backed_wrappers_match_the_executed_reference(orc
 @pytest.mark.parametrize("run", RUNS)
 def test_gpu_whole_runs_match_the_executed_reference(run):
     """The PRODUCT (libmbd_hip.so through the C ABI) against the same files: reset, then every recorded step teacher-forced —
-    key chain exact, rewards 1e-5, weights 1e-2 relative, Ybar_{i-1} 1e-5 — and rew_final of the file's final plan."""
+    key chain exact, rewards 1e-5, weights and Ybar_{i-1} to score_tol's bound — and rew_final of the file's final plan."""
     import ctypes as C
     import torch
     from mbd_hip import _capi
@@ -348,10 +376,11 @@ def test_gpu_whole_runs_match_the_executed_reference(run):
         _capi.check(plan.lib.mbd_plan_reverse_once(plan.h, int(g["i"][k]), key, d_Y.data_ptr(), d_rm.data_ptr(), None))
         torch.cuda.synchronize()
         assert [key[0], key[1]] == [int(x) for x in g["rng_out"][k]]
-        assert np.abs(d_Y.cpu().numpy().reshape(g["Ybar_im1"][k].shape) - g["Ybar_im1"][k]).max() < 1e-5, k
+        rtol_w, tol_Y = score_tol(g["rewss"][k], temp, sigma_of(int(g["i"][k]), Nd), demo)
+        assert np.abs(d_Y.cpu().numpy().reshape(g["Ybar_im1"][k].shape) - g["Ybar_im1"][k]).max() < tol_Y, (k, tol_Y)
         assert abs(float(d_rm.item()) - float(g["rew_mean"][k])) < 1e-5
         _, rewss, w = plan.peek()
-        assert np.abs(rewss - g["rewss"][k]).max() < 1e-5 and np.allclose(w, g["weights"][k], rtol=1e-2, atol=1e-8)
+        assert np.abs(rewss - g["rewss"][k]).max() < 1e-5 and np.allclose(w, g["weights"][k], rtol=rtol_w, atol=1e-8)
     assert abs(plan.eval(g["Ybar_im1"][-1]) - float(g["rew_final"])) < 1e-5
     plan.close()
 
@@ -385,8 +414,9 @@ def test_path_integral_runs_match_the_executed_reference(orc, run):
         assert np.abs(rewss - g["rewss"][k]).max() < 1e-5
         mu, sigma, w, rm = orc.pi_update(op.PI_METHODS[method], op.mean_h(orc, np.ascontiguousarray(rewss)), Y0s, g["mu_in"][k],
                                          float(g["sigma_in"][k]), temp)
-        assert np.allclose(w, g["weights"][k], rtol=1e-2, atol=1e-8)
-        assert np.abs(mu - g["mu_out"][k]).max() < 1e-5, (k, np.abs(mu - g["mu_out"][k]).max())
+        rtol_w, tol_mu = score_tol(g["rewss"][k], temp, float(g["sigma_in"][k]))
+        assert np.allclose(w, g["weights"][k], rtol=rtol_w, atol=1e-8), (k, rtol_w)
+        assert np.abs(mu - g["mu_out"][k]).max() < tol_mu, (k, np.abs(mu - g["mu_out"][k]).max(), tol_mu)
         assert abs(float(sigma) - float(g["sigma_out"][k])) <= 1e-4 * float(g["sigma_out"][k])
         assert abs(float(rm) - float(g["rew_mean"][k])) < 1e-5
         if k + 1 < len(g["t"]):
@@ -428,7 +458,8 @@ def test_gpu_path_integral_runs_match_the_executed_reference(run):
         _capi.check(plan.lib.mbd_plan_reverse_once(plan.h, int(g["t"][k]), key, d_Y.data_ptr(), d_rm.data_ptr(), None))
         torch.cuda.synchronize()
         assert [key[0], key[1]] == [int(x) for x in g["rng_out"][k]]
-        assert np.abs(d_Y.cpu().numpy().reshape(g["mu_out"][k].shape) - g["mu_out"][k]).max() < 1e-5, k
+        tol_mu = score_tol(g["rewss"][k], temp, float(g["sigma_in"][k]))[1]
+        assert np.abs(d_Y.cpu().numpy().reshape(g["mu_out"][k].shape) - g["mu_out"][k]).max() < tol_mu, k
         assert abs(plan.get_sigma() - float(g["sigma_out"][k])) <= 1e-4 * float(g["sigma_out"][k])
         assert abs(float(d_rm.item()) - float(g["rew_mean"][k])) < 1e-5
     assert abs(plan.eval(g["mu_out"][-1]) - float(g["rew_final"])) < 1e-5

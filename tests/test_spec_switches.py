@@ -26,18 +26,19 @@ def _roll(orc, m, steps=40, seed=0, scale=0.5):
 
 
 def test_flag_words():
-    assert spec_bits("contact_avg", "contact6_jacobi") == 12 and spec_names(16 | 128) == ["friction_vel_bound", "gyroscopic"]
+    assert spec_bits("contact_avg", "contact6_gauss_seidel") == 12 and spec_names(16 | 128) == ["friction_vel_bound", "gyroscopic"]
     assert sorted(SPEC_FLAGS.values()) == [4, 8, 16, 32, 64, 128]
 
 
 @pytest.mark.parametrize("name", ["humanoidrun", "hopper", "walker2d", "humanoidstandup"])
 def test_contact_switches_only_touch_links_with_several_contacts(orc, name):
-    """contact_avg / contact6_jacobi act on links with two or more ACTIVE contacts: the humanoids' feet carry one sphere
+    """contact_avg / contact6_gauss_seidel (stage (6) one contact after the other instead of the default, all from the same
+    velocities) act on links with two or more ACTIVE contacts: the humanoids' feet carry one sphere
     each — not a bit changes — while hopper's and walker2d's feet (two spheres: the planar restatement) and
     humanoidstandup's torso (five: the 3-D one) do once they stand / lie on both."""
     m = load_model(name)
     base = _roll(orc, m, 100, scale=0.1)  # (gentle actions: the models settle onto their feet / their back)
-    for bits in (spec_bits("contact_avg"), spec_bits("contact6_jacobi"), spec_bits("contact_avg", "contact6_jacobi")):
+    for bits in (spec_bits("contact_avg"), spec_bits("contact6_gauss_seidel"), spec_bits("contact_avg", "contact6_gauss_seidel")):
         got = _roll(orc, m.with_spec(bits), 100, scale=0.1)
         assert np.isfinite(got).all()
         if name == "humanoidrun":
@@ -62,13 +63,13 @@ def test_contact_avg_halves_the_correction_of_two_equal_contacts(orc):
 
 
 def test_jacobi_velocity_stage_sees_one_velocity(orc):
-    """contact6_jacobi: both runners of a pair compute their friction impulse from the same slip velocity, so a sled
-    sliding along x is braked by 4x one runner's impulse, while Gauss-Seidel gives every later runner a slower sled and
-    a smaller impulse (the bound binds first): the Jacobi sled loses at least as much speed in the step."""
+    """The default (Jacobi): all runners of the sled compute their friction impulse from the same slip velocity, so a sled
+    sliding along x is braked by 4x one runner's impulse, while contact6_gauss_seidel gives every later runner a slower sled
+    and a smaller impulse (the bound binds first): the Jacobi sled loses at least as much speed in the step."""
     m = _compile(SLED.format(gx=0.0, gz=-9.81, mu=1.0))
     st = None
     lost = {}
-    for tag, bits in (("gs", 0), ("jacobi", spec_bits("contact6_jacobi"))):
+    for tag, bits in (("jacobi", 0), ("gs", spec_bits("contact6_gauss_seidel"))):
         ms = m.with_spec(bits).to_struct()
         st = orc.forward(ms, m.init_q, np.zeros(6, np.float32))
         for _ in range(300):  # settle

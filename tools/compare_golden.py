@@ -5,7 +5,7 @@ i.e. which of DESIGN.md §9's guesses is wrong — after first comparing the com
     python tools/compare_golden.py tests/golden/golden_humanoidrun_N64_H50.npz [--tol 1e-5] [--flags N] [--search]
 
 --flags N   replay under the specification switches N (include/mbd_hip.h mbd_model_flags / mbd_hip.model.SPEC_FLAGS:
-            contact_avg 4, contact6_jacobi 8, friction_vel_bound 16, restitution_min 32, euler_extrinsic 64, gyroscopic 128)
+            contact_avg 4, contact6_gauss_seidel 8, friction_vel_bound 16, restitution_min 32, euler_extrinsic 64, gyroscopic 128)
 --search    replay under EVERY combination of the six switches and rank them: most stages within tolerance first, then the
             smallest error at the first mismatching stage, then the fewest switches — the line to read is the first one; a
             winner other than "default" names the code-level guesses of DESIGN.md §9 that Brax decides the other way, and
