@@ -194,6 +194,7 @@ def cpu_baseline(cfg, seconds_budget=15.0):
     ref_rec, ref_why = reference_baseline(cfg)
     port, fsub = port_baseline(cfg, seconds_budget)
     if ref_rec is not None:
+        ref_rec["_trajectory"] = port.pop("_trajectory")
         ref_rec["port"] = {k: port[k] for k in ("value", "cores", "physical_cores", "host", "phase_ms", "sample")}
         return ref_rec, fsub
     port["reference_attempt"] = ref_why
@@ -272,14 +273,19 @@ def port_baseline(cfg, seconds_budget=15.0):
     steps, t0 = 0, time.time()
     i = Nd - 1
     phases = {}
+    traj = {"seed": 0, "state_init": np.asarray(state0, np.float32), "mu_0ts": [], "rew_means": [], "rew_final": None}
     while True:
-        r, Ybar, _, _ = op.reverse_once(orc, env, state0, i, r, Ybar, sched, N, H, temp, 1, enable_demo=cfg["demo"],
-                                        timers=phases)
+        r, Ybar, rm, _ = op.reverse_once(orc, env, state0, i, r, Ybar, sched, N, H, temp, 1, enable_demo=cfg["demo"],
+                                         timers=phases)
+        traj["mu_0ts"].append(Ybar)      # (the plan of seed 0 from its first step on: what `parity` compares)
+        traj["rew_means"].append(rm)
         steps += 1
         i -= 1
         if time.time() - t0 > seconds_budget or i < 1:  # 10-15 s of host work, at most one whole plan
             break
     dt = time.time() - t0
+    if i < 1:  # the whole plan ran: its final evaluation too (mbd_planner.py:179-180), outside the timed sample
+        traj["rew_final"] = float(op.mean_h(orc, np.ascontiguousarray(env.rollout(state0, Ybar[None])))[0])
     try:  # physical cores beside the hardware threads OpenMP uses (SMT siblings share the FP units)
         import psutil
         physical = psutil.cpu_count(logical=False)
@@ -295,7 +301,32 @@ def port_baseline(cfg, seconds_budget=15.0):
             "host": cpu_info, "kind": "port", "phase_ms": phase_ms, "serial_share_upper_bound": serial / dt,
             "sample": f"{steps} consecutive reverse-diffusion steps of {name} N={N} H={H} "
                       f"(CPU oracle, OpenMP over candidates in sampler, rollout and weighted mean, {threads} threads = the CPUs "
-                      f"this container may use (affinity, cgroup quota), {dt:.1f} s)"}, fsub
+                      f"this container may use (affinity, cgroup quota), {dt:.1f} s)", "_trajectory": traj}, fsub
+
+
+def whole_run_parity(traj, gpu_details, gpu_rew_final):
+    """The `parity` object of the line: the plan of seed 0 as the GPU ran it (run_diffusion through the C
+    ABI) against the consecutive steps of the SAME plan the cpu_baseline leg's checker just ran — mu_0ts (Ybar after every
+    step), the per-step mean rewards and, when the checker ran the whole plan, rew_final (mbd_planner.py:138-151,179-180).
+    Not teacher-forced: step k sees what step k-1 left, on both sides.  Outside the timed region."""
+    import numpy as np
+    k = len(traj["mu_0ts"])
+    cm, cr = np.stack(traj["mu_0ts"]).astype(np.float32), np.asarray(traj["rew_means"], np.float32)
+    gm, gr = np.asarray(gpu_details["mu_0ts"], np.float32)[:k].reshape(cm.shape), np.asarray(gpu_details["rew_means"], np.float32)[:k]
+    same_init = bool(np.array_equal(np.asarray(gpu_details["state_init"].pipeline_state, np.float32).reshape(-1),
+                                    traj["state_init"].reshape(-1)))
+    eq = same_init and bool(np.array_equal(cm, gm)) and bool(np.array_equal(cr, gr))
+    den = np.maximum(np.abs(cm), 1e-6)
+    out = {"against": "cpu checker (oracle/, the separately written C restatement; NOT the JAX reference)", "plan": "seed 0 of the "
+           "line's config, free-running (every step from the previous step's own result)", "steps": int(k),
+           "quantities": "state_init, mu_0ts[:steps], rew_means[:steps]" + (", rew_final" if traj["rew_final"] is not None else ""),
+           "max_rel_mu": float((np.abs(cm - gm) / den).max()), "max_abs_rew_mean": float(np.abs(cr - gr).max())}
+    if traj["rew_final"] is not None:
+        out["rew_final_cpu"], out["rew_final_gpu"] = float(np.float32(traj["rew_final"])), float(np.float32(gpu_rew_final))
+        eq = eq and np.float32(traj["rew_final"]) == np.float32(gpu_rew_final)
+    out["bit_equal"] = bool(eq)
+    out["max_rel"] = max(out["max_rel_mu"], out["max_abs_rew_mean"])
+    return out
 
 
 def main():
@@ -347,6 +378,21 @@ def main():
             dist.init_process_group(backend)
         dist.barrier()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: launch through torch.distributed.run"
+    # the ranks the COLLECTIVE LIBRARY actually joined: a sum of ones through the process group itself (RCCL over xGMI with
+    # the nccl backend), and the distinct devices behind them — the line fails loudly when either is not --gpus
+    rccl_world = None
+    if distributed:
+        ones = torch.ones(1, dtype=torch.int32, device=torch.device("cuda", local_rank) if backend == "nccl" else "cpu")
+        dist.all_reduce(ones)
+        rccl_world = int(ones.item())
+        if rccl_world != world or dist.get_world_size() != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus}, WORLD_SIZE {world}, but the process group reduced over {rccl_world} "
+                             f"rank(s) (backend {backend})")
+        if backend == "nccl":
+            devs = [None] * world
+            dist.all_gather_object(devs, (os.environ.get("HOSTNAME", ""), local_rank))
+            if len(set(devs)) != world:
+                raise SystemExit(f"bench.py: {world} ranks share {len(set(devs))} device(s): {devs}")
 
     from mbd_hip import _capi
     from mbd_hip.envs import get_env
@@ -810,6 +856,25 @@ def main():
             if per_rank is not None:
                 out["per_rank_plan_steps_per_sec"] = per_rank
             n_valu = p_local * N_CFG
+        if distributed:
+            out["rccl_world"] = rccl_world
+            out["dist_backend"] = backend + (" (RCCL over xGMI)" if backend == "nccl" else " (dry run: ranks may share a device)")
+        # what a reader of the N = 1, 2, 4, 8 lines should expect BEFORE computing an efficiency from them (the driver does
+        # that itself from `value`): the literal metric shards ONE plan's N candidates, and a rollout is latency-bound —
+        # N / G candidates take as long as N while a launch leaves SIMDs idle (N <= 4096 on this chip)
+        out["scaling_expectation"] = {
+            "strong": "FLAT by design: phase 1 (sample + rollout) of N/G candidates costs what N do (one wavefront per SIMD "
+                      "either way: ~0.55 ms at any N/G <= 1024 for humanoidrun), plus one all-gather of N/G rewards per rank and "
+                      "step (~10-30 us): value(G) ~ value(1) x 0.93-0.97, efficiency ~ 1/G",
+            "weak": "N per GPU, G x N in total: ~0.95 of linear in candidates per second (the same phase 1 per rank, the score over "
+                    "G x N candidates recomputed on every rank: +8 us per 1024 candidates)",
+            "sweep8_replicas": "LINEAR: independent plans as replicas over the ranks (the reference's own sweep protocol, "
+                               "scripts/run_mbd.py:17-39), no collective inside a run — the workload of the reference that fills "
+                               "more than one GPU; `--config sweep8 --gpus G` is its fenced form, extras.sweep8_replicas the "
+                               "rider of the metric line",
+            "measured_on_hardware": "no run on more than one DEVICE exists yet (rounds 1-5: the driver's SCALE was skipped, no "
+                                    "8-GPU node); ranks > 1 have only run as processes sharing one GPU",
+        }
         if phase_ms is not None:
             out["phase_ms"] = phase_ms
         if other_coll is not None:
@@ -833,6 +898,16 @@ def main():
             out["cpu_baseline"], live = cpu_baseline(cfg)
             if live:
                 fsub, fsub_src = live, "oracle/count_ops.cc (this run)"
+            traj = out["cpu_baseline"].pop("_trajectory", None)
+            if traj is not None and not is_sweep and not os.environ.get("MBD_BENCH_N"):
+                try:  # (guarded like the extras: a failure here is reported, it never costs the line its value)
+                    a = Args(seed=0, env_name=ENV, Nsample=N_CFG, Hsample=H, Ndiffuse=ND, temp_sample=TEMP, enable_demo=DEMO,
+                             disable_recommended_params=True, not_render=True)
+                    with contextlib.redirect_stdout(sys.stderr):
+                        g_rf, g_det = run_diffusion(a, device=local_rank, return_details=True, force_single=True)
+                    out["parity"] = whole_run_parity(traj, g_det, g_rf)
+                except Exception as e:  # noqa: BLE001
+                    out["parity"] = {"error": f"{type(e).__name__}: {e}"}
         if is_sweep and n_valu <= 4096:  # (the one-candidate kernel's geometry and static counts)
             cfg = dict(cfg, cpw=4, static="humanoidrun")
         out["valu"] = valu_view(cfg, n_valu, kern_ms, n_frames, fsub, fsub_src)

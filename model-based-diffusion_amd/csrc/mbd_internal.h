@@ -204,7 +204,7 @@ bool env_flag(const char* name);
 int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B, int H, float* d_rewss, float* d_rews,
                    float* d_xpos, float* d_state_final, hipStream_t stream, LazyArgs* lz = nullptr, const int* sweep = nullptr);
 // whether a rollout launch of B candidates takes the next step's normals into spare workgroups
-bool rollout_fuses_noise(const mbd_env* env, int B);
+bool rollout_fuses_noise(const mbd_env* env, int B, bool allow_pk2 = true);  // (allow_pk2: false for sweeps whose plans hold an odd candidate count — launch_rollout)
 int launch_logpd(const mbd_env* e, const float* d_xpos, int B, int H, float* d_out, hipStream_t s);
 // ---- defined in mbd_plan.hip -----------------------------------------------------------------------------------------
 // noise schedule (mbd_planner.py:84-87)

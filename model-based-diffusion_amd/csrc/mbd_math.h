@@ -268,6 +268,21 @@ __device__ __forceinline__ void div2x2_(f2 na, f2 da, f2 nb, f2 db, f2& qa_out, 
   qa_out = fma2(ea, ra, qa); qb_out = fma2(eb, rb, qb);
 }
 
+// the same with SIGNED numerators in the first pair (flushed to zero below 1e-28 like div_) and non-negative ones in the
+// second (clamped like div_pos_): two div2_sp_-style quotients per half — the two contacts of a link in stage (6)
+__device__ __forceinline__ void div2x2_sp_(f2 na, f2 da, f2 nb, f2 db, f2& qa_out, f2& qb_out) {
+  na = mk2(fabs_(na.x) < 1e-28f ? 0.0f : na.x, fabs_(na.y) < 1e-28f ? 0.0f : na.y);
+  nb = mk2(fmax_(nb.x, 1e-28f), fmax_(nb.y, 1e-28f));
+  f2 ra = mk2(__builtin_amdgcn_rcpf(da.x), __builtin_amdgcn_rcpf(da.y));
+  f2 rb = mk2(__builtin_amdgcn_rcpf(db.x), __builtin_amdgcn_rcpf(db.y));
+  const f2 one = mk2(1.0f, 1.0f);
+  f2 ea = fma2(-da, ra, one), eb = fma2(-db, rb, one);
+  ra = fma2(ea, ra, ra); rb = fma2(eb, rb, rb);
+  f2 qa = na * ra, qb = nb * rb;
+  ea = fma2(-da, qa, na); eb = fma2(-db, qb, nb);
+  qa_out = fma2(ea, ra, qa); qb_out = fma2(eb, rb, qb);
+}
+
 // angle of the near-unit vector (c, s) in (-pi, pi], division-free: asin of min(|s|,|c|) + octant fix-ups.  The
 // result takes the SIGN BIT of s (one v_bfi instead of a compare and a select; a VALU compare holds a lone
 // wavefront's issue port for two slots).  The reflection about pi/2 stays a compare: the same trick there

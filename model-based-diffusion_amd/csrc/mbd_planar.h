@@ -494,8 +494,33 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         om = dqy * __builtin_copysignf(two_inv_dt, dqw);
       }
       // ---- (6) collisions.resolve_velocity (Jacobi per link) ---------------------------------------------------
-      if constexpr (MAXCOL > 0) {
-        const float vx6 = vx, vz6 = vz, om6 = om;  // what every contact of the link sees (SPEC, contact6_gauss_seidel: the running values)
+      // every contact of the link computes its impulse from the velocities stage (5) left; the changes are added in collider
+      // order (SPEC, contact6_gauss_seidel: one after the other, each from the running values)
+      if constexpr (MAXCOL == 2 && !SPEC) {
+        // both colliders of the link as one packed pair (Jacobi makes them independent), like stage (4)
+        const f2 rcx = mk2(cposx[0], cposx[1]) - bc2(px), rcz = mk2(cposz[0], cposz[1]) - bc2(pz);
+        const f2 vptx = fma2(bc2(om), rcz, bc2(vx)), vptz = fma2(bc2(-om), rcx, bc2(vz));
+        f2 vn_prev = bc2(0.0f);
+        if (FL >= 0 ? (FL & 4) != 0 : elast != 0.0f) vn_prev = fma2(bc2(-om_old), rcx, bc2(vz_old));  // (wave-uniform; with e = 0 the term is exactly 0)
+        const f2 vtn = __builtin_elementwise_abs(vptx);
+        const f2 icn = rcx * bc2(iy_c);
+        const f2 wn = fma2(icn, rcx, bc2(im_c));
+        const f2 wt = fma2(rcz, rcz * bc2(iy_c), bc2(im_c));
+        const f2 rest = bc2(-elast) * vn_prev;
+        const f2 dvn = mk2(fmax_(rest.x, 0.0f), fmax_(rest.y, 0.0f)) - vptz;
+        const f2 jt_max = (bc2(mu) * mk2(cdlam[0], cdlam[1])) * bc2(inv_dt);
+        const f2 jw = jt_max * wt;
+        const f2 dvt = mk2(fmin_(jw.x, vtn.x), fmin_(jw.y, vtn.y));
+        f2 q_n, q_t;
+        div2x2_sp_(dvn, wn, dvt, wt, q_n, q_t);
+        const f2 Pix = mk2(-__builtin_copysignf(q_t.x, vptx.x), -__builtin_copysignf(q_t.y, vptx.y)), Piz = q_n;  // friction opposes the slip
+        const f2 dom = pl_cross2(rcx, rcz, Pix, Piz) * bc2(iy_c);
+        const float nvx0 = ffma(im_c, Pix.x, vx), nvz0 = ffma(im_c, Piz.x, vz), nom0 = om + dom.x;
+        vx = cact[0] ? nvx0 : vx; vz = cact[0] ? nvz0 : vz; om = cact[0] ? nom0 : om;
+        const float nvx1 = ffma(im_c, Pix.y, vx), nvz1 = ffma(im_c, Piz.y, vz), nom1 = om + dom.y;
+        vx = cact[1] ? nvx1 : vx; vz = cact[1] ? nvz1 : vz; om = cact[1] ? nom1 : om;
+      } else if constexpr (MAXCOL > 0) {
+        const float vx6 = vx, vz6 = vz, om6 = om;  // what every contact of the link sees
 #pragma unroll
         for (int j = 0; j < MAXCOL; ++j) {
           const float rcx = cposx[j] - px, rcz = cposz[j] - pz;

@@ -80,9 +80,13 @@ class _EnvBase:
 
     def pipeline_init(self, q, qd=None):
         """PipelineEnv.pipeline_init(q, qd) (humanoidrun.py:29): the pipeline state of generalized coordinates — what
-        ``Plan.set_state0`` / ``rollout_us`` take; a state to plan from that is not a reset."""
+        ``Plan.set_state0`` / ``rollout_us`` take; a state to plan from that is not a reset.  ``qd=None``: at rest (zeros of
+        the model's qd size; car2d has no velocities)."""
         q = np.ascontiguousarray(q, np.float32).reshape(-1)
-        qd = np.zeros(0, np.float32) if qd is None else np.ascontiguousarray(qd, np.float32).reshape(-1)
+        if qd is None:
+            sys_ = getattr(self, "sys", None)
+            qd = np.zeros(sys_.qd_size() if sys_ is not None else 0, np.float32)
+        qd = np.ascontiguousarray(qd, np.float32).reshape(-1)
         st = np.zeros(self._state_size, np.float32)
         _capi.check(self._lib.mbd_env_pipeline_init(self._h, _capi.np_ptr(q), q.size, _capi.np_ptr(qd) if qd.size else None,
                                                     qd.size, _capi.np_ptr(st)))

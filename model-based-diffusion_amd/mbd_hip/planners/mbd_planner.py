@@ -377,7 +377,17 @@ def reverse_distributed(plan: Plan, key, device, group=None, sync_every_step: bo
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if phase_times is not None else None
     acc = [0.0, 0.0, 0.0]
     collective = collective or os.environ.get("MBD_COLLECTIVE", "torch")
-    p2p = P2PExchange(device, rows, sh, group) if (world > 1 and collective == "p2p") else None
+    p2p = None
+    if world > 1 and collective == "p2p":
+        # the constructor agrees on a failure across the ranks (all raise, or none): a runtime without fine-grained device
+        # memory or peer mappings (mbd_exchange_create: MBD_ERR_UNSUPPORTED) falls back — on EVERY rank — to the collective
+        # library's all-gather, as include/mbd_hip.h tells the caller to; same values either way
+        try:
+            p2p = P2PExchange(device, rows, sh, group)
+        except _capi.MbdError as e:
+            import warnings
+            warnings.warn(f"in-library exchange unavailable ({e}): falling back to torch.distributed all-gather")
+            p2p = None
     host = HostProgress(plan.Nd - 1, dev) if (sync_every_step or progress is not None) else None
     # Host work that does not depend on the GPU — the key chain (rng, Y0s_rng = split(rng), mbd_planner.py:103) and the
     # declaration of the FOLLOWING step's key (its normals are generated beside this step's rollout) — is done while

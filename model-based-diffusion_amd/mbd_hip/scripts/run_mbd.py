@@ -180,6 +180,8 @@ def run_path_integral_sweep(arg_list, device: int = 0, return_details: bool = Fa
     import io
     from ..planners import path_integral
     from ..planners.mbd_planner import Sweep
+    if len(arg_list) == 0:
+        return (np.zeros(0, np.float32), 0.0, {}) if return_details else (np.zeros(0, np.float32), 0.0)
     impl = prng_impl()
     resolved = []
     for a in arg_list:
@@ -214,15 +216,29 @@ def run_path_integral_sweep(arg_list, device: int = 0, return_details: bool = Fa
     return np.array(rews), secs
 
 
+def _local_device(device):
+    """The GPU a sweep of this process runs on: the argument, else LOCAL_RANK under torch.distributed.run, else 0."""
+    import os
+    return int(os.environ.get("LOCAL_RANK", "0")) if device is None else device
+
+
+def _time_line(secs, n_plans):
+    """The reference prints `time: mean \\pm std` over its eight sequential runs (run_mbd.py:39); a lockstep batch has one
+    wall time, so every plan's share is the same and the spread is 0 — printed in the reference's format, the batch beside it."""
+    per = secs / max(n_plans, 1)
+    return f"time: {per:.2f} \\pm {0.0:.2f} (per plan; {secs:.2f} s for the lockstep batch of {n_plans})"
+
+
 def run_multiple_seed(args: Args, device: int | None = None, **plan_kw):
     """run_mbd.py:17-39: seeds 0..7, mean +- std of the final reward and the time."""
     if args.algo == "path_integral":  # :22-26
         from ..planners import path_integral
         plans = [path_integral.Args(seed=seed, env_name=args.env_name, update_method=args.update_method, **plan_kw)
                  for seed in range(8)]
-        rews, secs = run_path_integral_sweep(plans, device or 0)  # (one sweep: one rollout launch per refinement step)
+        # (one sweep on this process's GPU: one rollout launch per refinement step)
+        rews, secs = run_path_integral_sweep(plans, _local_device(device))
         print(f"rew: {rews.mean():.2f} \\pm {rews.std():.2f}")
-        print(f"time: {secs / len(plans):.2f} per plan ({secs:.2f} s for the batch of {len(plans)})")
+        print(_time_line(secs, len(plans)))
         return rews, float(secs)
     if args.algo != "mbd":
         raise NotImplementedError  # :32-33
@@ -230,7 +246,7 @@ def run_multiple_seed(args: Args, device: int | None = None, **plan_kw):
     rews, _, secs = run_replicated(plans, device)  # (one GPU: run_concurrent; several: the plans as replicas over ranks)
     rews = np.array(rews)
     print(f"rew: {rews.mean():.2f} \\pm {rews.std():.2f}")
-    print(f"time: {secs / len(plans):.2f} per plan ({secs:.2f} s for the concurrent batch of {len(plans)})")
+    print(_time_line(secs, len(plans)))
     return rews, secs
 
 
@@ -241,7 +257,8 @@ def run_multiple_temp(args: Args, device: int | None = None, **plan_kw):
     if args.algo == "path_integral":
         from ..planners import path_integral
         rews, _ = run_path_integral_sweep(
-            [path_integral.Args(seed=0, env_name=args.env_name, temp_sample=float(t), **plan_kw) for t in temps], device or 0)
+            [path_integral.Args(seed=0, env_name=args.env_name, temp_sample=float(t), **plan_kw) for t in temps],
+            _local_device(device))
     elif args.algo == "mbd":
         plans = [mbd_planner.Args(seed=0, env_name=args.env_name, temp_sample=float(t), not_render=True,
                                   disable_recommended_params=True, **plan_kw) for t in temps]

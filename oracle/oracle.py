@@ -47,6 +47,20 @@ def count_substep(model_struct, state, action):
     return d, out
 
 
+def depth_substeps(model_struct, state, action, n_sub: int = 8):
+    """Dependency depth of n_sub consecutive substeps (oracle/count_ops.cc orc_depth_substeps): an array [n_sub][L + 1] —
+    per link, and in the last column over all links — of the longest chain of dependent operations behind the state after
+    each substep, in issue slots of the kernels' sequences (division 7, square root 5, everything else 1)."""
+    build()
+    lib = C.CDLL(os.path.join(_BUILD, "liboracle_count.so"))
+    lib.orc_depth_substeps.argtypes = [C.c_void_p, _f32p, _f32p, C.c_int, np.ctypeslib.ndpointer(np.uint32)]
+    L = int(model_struct.n_links)
+    out = np.zeros((n_sub, L + 1), np.uint32)
+    lib.orc_depth_substeps(C.addressof(model_struct), np.ascontiguousarray(state, np.float32).reshape(-1),
+                           np.ascontiguousarray(action, np.float32), n_sub, out)
+    return out
+
+
 class Oracle:
     def __init__(self, variant: str = "f32"):
         path = os.path.join(_BUILD, f"liboracle_{variant}.so")

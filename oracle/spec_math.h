@@ -24,29 +24,40 @@
 #endif
 typedef ORC_REAL real;
 #define R(x) ((real)(x))
+#ifndef ORC_REAL_IS_F32
+#define ORC_REAL_IS_F32 (sizeof(real) == 4)
+#endif
 
+/* (ORC_CUSTOM_PRIMS: oracle/count_ops.cc supplies sp_fma / sp_sqrt / sp_abs / sp_copysign on its counting wrapper type —
+ * the same values, plus op counts and dependency depth) */
+#ifndef ORC_CUSTOM_PRIMS
 static inline real sp_fma(real a, real b, real c) {
-  return sizeof(real) == 4 ? (real)__builtin_fmaf((float)a, (float)b, (float)c)
+  return ORC_REAL_IS_F32 ? (real)__builtin_fmaf((float)a, (float)b, (float)c)
                            : (real)__builtin_fma((double)a, (double)b, (double)c);
 }
 static inline real sp_sqrt(real x) {
-  return sizeof(real) == 4 ? (real)__builtin_sqrtf((float)x) : (real)__builtin_sqrt((double)x);
+  return ORC_REAL_IS_F32 ? (real)__builtin_sqrtf((float)x) : (real)__builtin_sqrt((double)x);
 }
+#endif
 /* the solver's square root (cos of the middle Euler angle, tangential contact speed): the argument is clamped from
  * below at 1e-30 (result >= 1e-15), everything else is the correctly rounded root.  (The clamp lets the kernels
  * use the 8-instruction rsq + FMA sequence, which tools/probes/probe_sqrt.hip shows bit-identical to sqrtf on EVERY
  * float32 in [1e-30, FLT_MAX], instead of the 16-instruction expansion that also covers denormal inputs; a clamp
  * rather than a flush because one v_max is cheaper than a compare and a select.) */
 static inline real sp_sqrt_floor(real x) { return sp_sqrt(x < R(1e-30) ? R(1e-30) : x); }
-static inline real sp_abs(real x) { return sizeof(real) == 4 ? (real)__builtin_fabsf((float)x) : (real)__builtin_fabs((double)x); }
+#ifndef ORC_CUSTOM_PRIMS
+static inline real sp_abs(real x) { return ORC_REAL_IS_F32 ? (real)__builtin_fabsf((float)x) : (real)__builtin_fabs((double)x); }
 /* |mag| with the SIGN BIT of sgn (so -0.0 counts as negative): one bit select on the GPU, no compare */
 static inline real sp_copysign(real mag, real sgn) {
-  return sizeof(real) == 4 ? (real)__builtin_copysignf((float)mag, (float)sgn)
+  return ORC_REAL_IS_F32 ? (real)__builtin_copysignf((float)mag, (float)sgn)
                            : (real)__builtin_copysign((double)mag, (double)sgn);
 }
+#endif
+#ifndef ORC_CUSTOM_PRIMS
 static inline real sp_min(real a, real b) { return a < b ? a : b; }
 static inline real sp_max(real a, real b) { return a > b ? a : b; }
 static inline real sp_clip(real v, real lo, real hi) { return v < lo ? lo : (v > hi ? hi : v); }
+#endif
 
 /* the solver's division: numerators below 1e-28 in magnitude are flushed to zero (physically nothing; it keeps
  * every quotient and residual a normal number, which is what lets the GPU use the bare reciprocal/FMA
@@ -201,7 +212,7 @@ static inline void sp_qrotvec_raw(real q[4], const real th[3]) {
 
 /* sin & cos, |x| < ~1e4: Cody–Waite reduction by pi/2 with fma, cephes sinf/cosf minimax kernels */
 static inline void sp_sincos(real x, real* s_out, real* c_out) {
-  real k = sizeof(real) == 4 ? (real)__builtin_rintf((float)(x * R(0.63661977236758134308)))
+  real k = ORC_REAL_IS_F32 ? (real)__builtin_rintf((float)(x * R(0.63661977236758134308)))
                              : (real)__builtin_rint((double)(x * R(0.63661977236758134308)));
   real r = sp_fma(-k, R(1.5703125), x);                   /* pi/2 split in three parts */
   r = sp_fma(-k, R(4.837512969970703125e-4), r);

@@ -76,3 +76,32 @@ def test_reference_branch_with_stub_modules(bench_mod, tmp_path, monkeypatch):
             sys.modules.pop(m, None)
         if str(ref) in sys.path:
             sys.path.remove(str(ref))
+
+
+def test_whole_run_parity_record(bench_mod):
+    """bench.py's `parity` object: bit equality of the checker's consecutive steps with the GPU's run of the same plan, and
+    the size of a difference when there is one."""
+    import types
+
+    import numpy as np
+    g = np.random.default_rng(0)
+    mu = g.normal(size=(5, 4, 3)).astype(np.float32)
+    rm = g.normal(size=5).astype(np.float32)
+    st = g.normal(size=(2, 13)).astype(np.float32)
+    traj = {"seed": 0, "state_init": st, "mu_0ts": list(mu[:3]), "rew_means": list(rm[:3]), "rew_final": None}
+    det = {"mu_0ts": mu, "rew_means": rm, "state_init": types.SimpleNamespace(pipeline_state=st.copy())}
+    rec = bench_mod.whole_run_parity(traj, det, 0.5)
+    assert rec["bit_equal"] is True and rec["steps"] == 3 and rec["max_rel"] == 0.0 and "rew_final_cpu" not in rec
+    traj["mu_0ts"], traj["rew_means"], traj["rew_final"] = list(mu), list(rm), 0.5
+    assert bench_mod.whole_run_parity(traj, det, 0.5)["bit_equal"] is True
+    assert bench_mod.whole_run_parity(traj, det, 0.25)["bit_equal"] is False
+    mu2 = mu.copy()
+    mu2[4, 0, 0] *= np.float32(1.0 + 2e-5)
+    rec = bench_mod.whole_run_parity(traj, dict(det, mu_0ts=mu2), 0.5)
+    assert rec["bit_equal"] is False and 1e-5 < rec["max_rel"] < 1e-4
+
+
+def test_port_baseline_hands_its_trajectory_to_the_parity_leg(bench_mod):
+    port, _ = bench_mod.port_baseline(bench_mod.CONFIGS["car2d"], seconds_budget=30.0)
+    tr = port["_trajectory"]
+    assert len(tr["mu_0ts"]) == 49 and tr["rew_final"] is not None and tr["state_init"].shape[-1] == 3

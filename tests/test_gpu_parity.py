@@ -447,6 +447,34 @@ def test_run_diffusion_humanoidrun_end_to_end_short(gpu, orc):
     assert np.float32(rew) == np.float32(ref["rew_final"])
 
 
+@pytest.mark.parametrize("name,N,H,Nd,temp,demo,seed", [
+    ("humanoidrun", 1024, 50, 100, 0.1, False, 0),       # the metric's plan (what bench.py's `parity` compares, seed 0)
+    ("hopper", 512, 50, 100, 0.1, False, 1),             # BASELINE config 2
+    ("halfcheetah", 1024, 50, 100, 0.4, False, 2),       # config 3
+    ("humanoidtrack", 2048, 50, 100, 0.1, True, 3),      # config 5's plan on one GPU
+    ("humanoidrun", 4096, 50, 40, 0.1, False, 4)])       # config 4's size, 39 steps
+def test_whole_runs_at_full_size_bitexact(gpu, orc_omp, name, N, H, Nd, temp, demo, seed):
+    """WHOLE planning runs at the full size of the BASELINE configs, free-running (every step from the previous step's own
+    result, mbd_planner.py:138-151) and the final evaluation (:179-180): the product's run_diffusion through the C ABI against
+    the checker's (OpenMP over candidates: 1-10 s each) — reset state, mu_0ts of every step, every step's mean reward and
+    rew_final, bit for bit.  (Round 4 held whole runs only at N = 64, H = 20 and full sizes only teacher-forced.)"""
+    from mbd_hip.planners.mbd_planner import Args, run_diffusion
+    from mbd_hip.envs import get_env
+    from oracle import planner as op
+    args = Args(seed=seed, env_name=name, Nsample=N, Hsample=H, Ndiffuse=Nd, temp_sample=temp, enable_demo=demo,
+                disable_recommended_params=True, not_render=True)
+    rew, det = run_diffusion(args, return_details=True)
+    env = get_env(name)
+    ref = op.run_diffusion(orc_omp, _oenv(orc_omp, env), seed, N, H, Nd, temp, enable_demo=demo)
+    assert np.array_equal(np.asarray(det["state_init"].pipeline_state, np.float32).reshape(-1), ref["state_init"].reshape(-1))
+    got = np.asarray(det["mu_0ts"], np.float32).reshape(ref["mu_0ts"].shape)
+    first = next((k for k in range(len(got)) if not np.array_equal(got[k], ref["mu_0ts"][k])), None)
+    assert first is None, f"{name}: mu_0ts differ from step {first} on (max |d| there {np.abs(got[first] - ref['mu_0ts'][first]).max()})"
+    assert np.array_equal(np.asarray(det["rew_means"], np.float32), ref["rew_means"])
+    assert np.float32(rew) == np.float32(ref["rew_final"])
+    assert np.ptp(ref["rew_means"]) > 1e-3 and len(got) == Nd - 1
+
+
 def test_full_size_properties_humanoidrun(gpu):
     """BASELINE metric size (N=1024, H=50): size-independent properties instead of the oracle —
     determinism across runs, weights sum to 1, finite rewards, and shard-layout independence."""
