@@ -687,7 +687,9 @@ def test_pipeline_init_is_the_checkers_forward_kinematics_and_plans_start_from_i
     with pytest.raises(Exception):
         env.pipeline_init(q[:-1], qd)
     with pytest.raises(Exception):
-        env.pipeline_init(q)
+        env.pipeline_init(q, qd[:-1])
+    # qd omitted: at rest (round 5, advice: the optional argument used to work for car2d only)
+    assert np.array_equal(np.asarray(env.pipeline_init(q), np.float32), np.asarray(env.pipeline_init(q, np.zeros_like(qd)), np.float32))
 
 
 def test_render_outputs_mu0ts_and_replay(gpu, tmp_path, monkeypatch):
