@@ -136,7 +136,22 @@ def valu_view(cfg, n_local, kern_ms, n_frames, fsub, fsub_src):
         fl = ent["fp32_flops_per_lane_substep"] * 64.0 * waves * substeps
         out["issued"] = {"flops_per_launch": fl, "achieved": fl / (kern_ms * 1e-3) / 1e12,
                          "frac": fl / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TF,
-                         "valu_instr_per_wave_substep": ent["valu_per_substep"], "source": src}
+                         "valu_instr_per_wave_substep": ent["valu_per_substep"],
+                         "instr_per_wave_substep": ent["instructions_per_substep"], "source": src}
+    # the latency floor, measured (tools/critical_path.py: the op counter tracks the depth of every value's chain): the
+    # longest chain of DEPENDENT operations of one substep of one candidate.  x 4 clocks per dependent issue x the
+    # launch's substeps = the time of this rollout on a machine with unlimited lanes per candidate; the kernel issues
+    # `instr_per_wave_substep` instructions where `critical_path_ops` are on the chain — the rest is parallelism that
+    # lives in vector components and (parent, child) pairs, harvested two-wide by v_pk_* (docs/experiments.md §5:
+    # the component-per-lane probe measured 1.09x, the two-wavefront pipeline 1.10x at best)
+    cp, cp_src = committed("critical_path.json")
+    cpe = (cp or {}).get(cfg["env"])
+    if cpe:
+        out["critical_path_ops"] = cpe["depth_per_substep"]
+        out["critical_path"] = {"ops_per_substep": cpe["depth_per_substep"], "unit": (cp or {}).get("unit"),
+                                "floor_ms_at_4clk_2p4GHz": cpe["depth_per_substep"] * 4.0 * substeps / 2.4e9 * 1e3,
+                                "kernel_over_floor": kern_ms / (cpe["depth_per_substep"] * 4.0 * substeps / 2.4e9 * 1e3),
+                                "ops_per_link_over_depth": cpe["ops_per_link_over_depth"], "source": cp_src}
     return out
 
 

@@ -565,10 +565,10 @@ def run_brax(orc, env_name, seed, N, H, Nd, temp, demo):
                        "or Brax)" % env_name)
     for key in ("i", "rng_in", "rng_out", "Ybar_i", "Ybar_im1", "rew_mean", "rewss", "logp0", "weights"):
         out[key] = np.stack([np.asarray(st[key]) for st in REC["steps"]])
-    out["eps"] = np.stack([np.asarray(st["eps"]) for st in REC["steps"][:1]])
+    out["eps"] = np.stack([np.asarray(st["eps"])[:32] for st in REC["steps"][:1]])   # (the first 32 candidates' normals: file size)
     if demo:   # the tracked links' positions of the first step (what eval_xref_logpd read), in the wrapper's own order
         env = importlib.import_module("mbd.envs").get_env(env_name)
-        out["xpos_tracked"] = np.asarray(REC["steps"][0]["qs"])[:, :, np.asarray(env.track_body_idx)]
+        out["xpos_tracked"] = np.asarray(REC["steps"][0]["qs"])[:64, :, np.asarray(env.track_body_idx)]   # (64 candidates: file size)
     path = os.path.join(ROOT, "tests", "golden", f"ref_run_{env_name}{'_demo' if demo else ''}.npz")
     np.savez_compressed(path, **out)
     print(f"wrote {path}: {len(REC['steps'])} steps, rew_final = {float(rew_final):.6f}")
@@ -617,12 +617,23 @@ def main():
     orc_key = lambda seed: orc.split(orc.prng_key(seed), 2, 1)[1]   # rng_reset of mbd_planner.py:79
     env_resets()
     env_obs(orc)
-    for env_name, N, H, Nd, demo in (("humanoidrun", 32, 20, 6, False), ("hopper", 24, 12, 5, False), ("walker2d", 16, 10, 4, False),
-                                     ("humanoidstandup", 16, 12, 4, False), ("cartpole", 32, 20, 5, False),
-                                     ("humanoidtrack", 16, 20, 4, False), ("humanoidtrack", 16, 50, 4, True)):
+    # config 1 with --enable_demo: impossible at H = 30 (the demo has 50 rows, car2d.py:96-102) — what the reference does
+    # with it is part of the record (it raises; the product refuses the plan: mbd_plan_create, MBD_ERR_INVALID)
+    try:
+        run(ref, "demo_h30", 0, 128, 30, 50, 0.1, True)
+        rec = dict(raised=False, error="")
+    except Exception as e:  # noqa: BLE001
+        rec = dict(raised=True, error=f"{type(e).__name__}: {e}")
+    np.savez_compressed(os.path.join(ROOT, "tests", "golden", "ref_car2d_demo_h30.npz"), N=128, H=30, Nd=50, **rec)
+    print("config 1 with enable_demo at H=30:", rec)
+    # round 5: N >= 256 and >= 10 recorded steps per wrapper (round 4: N = 16-48, 3-5 steps), and the
+    # demo-conditioned score at config 5's N = 2048 (H = 50 is the demo's length; 2 steps: 2 x 102 400 env steps in Python)
+    for env_name, N, H, Nd, demo in (("humanoidrun", 256, 20, 11, False), ("hopper", 256, 12, 11, False), ("walker2d", 256, 10, 11, False),
+                                     ("humanoidstandup", 256, 12, 11, False), ("cartpole", 256, 20, 11, False),
+                                     ("humanoidtrack", 256, 20, 11, False), ("humanoidtrack", 2048, 50, 3, True)):
         run_brax(orc, env_name, 1, N, H, Nd, 0.1, demo)
-    for env_name, method, N, H, Nr in (("hopper", "mppi", 48, 15, 6), ("hopper", "cma-es", 48, 15, 6), ("hopper", "cem", 48, 15, 6),
-                                       ("humanoidrun", "mppi", 32, 10, 4), ("humanoidrun", "cma-es", 32, 10, 4)):
+    for env_name, method, N, H, Nr in (("hopper", "mppi", 256, 15, 11), ("hopper", "cma-es", 256, 15, 11), ("hopper", "cem", 256, 15, 11),
+                                       ("humanoidrun", "mppi", 256, 10, 11), ("humanoidrun", "cma-es", 256, 10, 11)):
         run_brax_pi(orc, env_name, method, 2, N, H, Nr, 0.1)
 
 
