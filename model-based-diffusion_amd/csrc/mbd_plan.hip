@@ -385,10 +385,18 @@ extern "C" int mbd_plan_score_update(mbd_plan* p, int i, const uint32_t key_samp
   } else {  // MBD (:128-133), mppi (:33-36), cma-es (:39-45)
     const int lit = c.update_method == 0 ? c.literal_score : 0;
     if (fused_score) {
-      hipLaunchKernelGGL(score_wmean_kernel, dim3((HNu + kWmE - 1) / kWmE), dim3(kWmE * kWmG), sizeof(float) * (size_t)N,
+      // XCD pinning (mbd_step_kernels.h pinned_tile): the T tiles on the fewest XCDs X in {1, 2, 4, 8} that give every tile
+      // a CU of its own (32 per XCD) and keep an XCD's share of the candidates' rows within its 4 MB L2; the launch is
+      // 8 ceil(T / X) workgroups long, those of the other XCDs leave at once.  MBD_WMEAN_XCDS = 1 / 2 / 4 / 8 forces X.
+      const int T = (HNu + kWmE - 1) / kWmE;
+      int X = 1;
+      while (X < 8 && ((T + X - 1) / X > 32 || (size_t)N * HNu * sizeof(float) / X > (size_t)4 << 20)) X *= 2;
+      const int x_env = lever("MBD_WMEAN_XCDS");
+      if (x_env == 1 || x_env == 2 || x_env == 4 || x_env == 8) X = x_env;
+      hipLaunchKernelGGL(score_wmean_kernel, dim3(8 * ((T + X - 1) / X)), dim3(kWmE * kWmG), sizeof(float) * (size_t)N,
                          s, d_rews_all, c.enable_demo ? d_logpd_all : nullptr, N, p->env->rew_xref, c.temp_sample,
                          c.update_method == 0 ? 1 : 0, p->d_weights, d_rew_mean, d_cand, HNu, d_Ybar_i, p->alphas[i],
-                         p->alphas_bar[i], p->alphas_bar[i - 1], lit, d_Ybar_im1, lazy, sigma_i, p->d_ybar_keep);
+                         p->alphas_bar[i], p->alphas_bar[i - 1], lit, d_Ybar_im1, lazy, sigma_i, p->d_ybar_keep, T, X);
     } else if (split) {
       hipLaunchKernelGGL(wmean_partial_kernel, dim3((HNu + kWmT - 1) / kWmT, kWmG), dim3(kWmT), 0, s, p->d_weights,
                          d_cand, N, HNu, p->d_wm_partial, lazy, sigma_i, d_Ybar_i);

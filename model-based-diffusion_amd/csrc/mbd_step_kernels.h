@@ -462,7 +462,14 @@ static __global__ __launch_bounds__(kWmE * kWmG) void wmean_kernel(const float* 
 // the LDS array the weighted mean reads them from; workgroup 0 also stores them and the step's mean reward.  A kernel
 // of a few microseconds is mostly launch latency (an empty kernel takes 4 us on the timeline): one launch instead of
 // two takes ~3.5 us off every step, and the rows of the candidates are already in flight while the weights are derived.
-template <int ROUND, bool REGS>  // rows in flight per round of the chain, score_block's REGS (48, true: one plan; sweeps: 32, false)
+// V (round 5): outputs per thread — a workgroup owns 16 V CONSECUTIVE outputs (64 V bytes of every candidate row), thread
+// (g, j) runs the V chains of outputs j V .. j V + V - 1 over its candidates n = g, g + 64, ...: the chains, their order and
+// the order of the 64 partials are the contract's whatever V is (same bits).  What V changes is how many 128-byte lines a
+// row segment shares with the tiles next door: a 64-byte segment touches 1.5 lines on average and shares each with a
+// neighbour — when the neighbours drift apart in time and the line has left the L2 in between it is fetched twice (the sweep's
+// batch form: 2.0x its algorithmic bytes, PMC round 4); a 256-byte segment touches 3 lines for 2 lines' worth of data:
+// 1.5x at worst, whatever the L2 does.
+template <int ROUND, bool REGS, int V = 1>  // rows in flight per round of the chain, score_block's REGS (48, true: one plan; sweeps: 32, false)
 __device__ __forceinline__ void score_wmean_body(
     const float* __restrict__ rews, const float* __restrict__ lp_demo, int N, float rew_xref, float temp, int std_guard,
     float* __restrict__ weights_out, float* __restrict__ rew_mean_out, const float* __restrict__ Y0s, int HNu,
@@ -473,19 +480,26 @@ __device__ __forceinline__ void score_wmean_body(
   static_assert(kWmE * kWmG == kScoreThreads, "score_block runs on the weighted mean's workgroup");
   extern __shared__ __attribute__((aligned(16))) float wl[];  // logp0, then the N weights
   __shared__ float red_s[2 * (kScoreThreads / 64)];
-  __shared__ float red[kWmG][kWmE + 1];
+  __shared__ float red[kWmG][kWmE * V + 1];
   const int j = threadIdx.x & (kWmE - 1), g = threadIdx.x / kWmE;
-  const int e_raw = tile * kWmE + j;
-  const int e = e_raw < HNu ? e_raw : HNu - 1;
-  const float* __restrict__ col = Y0s + e;
-  const float yb = lazy ? Ybar_i[e] : 0.0f;
-  auto val = [&](float x) { return lazy ? fclip(x * sigma + yb, -1.0f, 1.0f) : x; };
-  // the first 16 rows of this thread's chain leave now and land while the weights are derived
-  constexpr int PRE = 16;
-  const bool pre = g + (PRE - 1) * kWmG < N;
-  float y0[PRE];
+  const int e0 = tile * (kWmE * V) + j * V;  // this thread's first output
+  int e[V];
+  float yb[V];
 #pragma unroll
-  for (int k = 0; k < PRE; ++k) y0[k] = pre ? col[(size_t)(g + k * kWmG) * HNu] : 0.0f;
+  for (int v = 0; v < V; ++v) {
+    e[v] = e0 + v < HNu ? e0 + v : HNu - 1;
+    yb[v] = lazy ? Ybar_i[e[v]] : 0.0f;
+  }
+  auto val = [&](float x, int v) { return lazy ? fclip(x * sigma + yb[v], -1.0f, 1.0f) : x; };
+  // the first rows of this thread's chains leave now and land while the weights are derived
+  constexpr int PRE = 16 / V;
+  const bool pre = g + (PRE - 1) * kWmG < N;
+  float y0[PRE][V];
+#pragma unroll
+  for (int k = 0; k < PRE; ++k) {
+#pragma unroll
+    for (int v = 0; v < V; ++v) y0[k][v] = pre ? Y0s[(size_t)(g + k * kWmG) * HNu + e[v]] : 0.0f;
+  }
   __builtin_amdgcn_sched_barrier(0);
   float rew_mean;
   // the step's mean reward may go to a pinned host slot the host is polling (per-step progress, mbd_planner.py:147):
@@ -499,43 +513,73 @@ __device__ __forceinline__ void score_wmean_body(
     if (writer) weights_out[i] = w;
   }
   __syncthreads();
-  float acc = 0.0f;
-  int n = g;
-  if (pre) {  // (the chain over n is sequential by contract: the prefetched rows are its first 16 terms)
+  float acc[V];
 #pragma unroll
-    for (int k = 0; k < PRE; ++k) acc = ffma(wl[n + k * kWmG], val(y0[k]), acc);
+  for (int v = 0; v < V; ++v) acc[v] = 0.0f;
+  int n = g;
+  if (pre) {  // (the chain over n is sequential by contract: the prefetched rows are its first terms)
+#pragma unroll
+    for (int k = 0; k < PRE; ++k) {
+      const float w = wl[n + k * kWmG];
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] = ffma(w, val(y0[k][v], v), acc[v]);
+    }
     n += PRE * kWmG;
   }
   // (a round = the rows in flight at once, then their dependent fma chain: large plans are bound by the number of rounds —
   // 48 rows per round: N = 4096 one round behind the prefetch instead of two, N = 8192 three instead of four)
-  for (; n + (ROUND - 1) * kWmG < N; n += ROUND * kWmG) {
-    float y[ROUND];
+  constexpr int RND = ROUND / V;
+  for (; n + (RND - 1) * kWmG < N; n += RND * kWmG) {
+    float y[RND][V];
 #pragma unroll
-    for (int k = 0; k < ROUND; ++k) y[k] = col[(size_t)(n + k * kWmG) * HNu];
+    for (int k = 0; k < RND; ++k) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) y[k][v] = Y0s[(size_t)(n + k * kWmG) * HNu + e[v]];
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < ROUND; ++k) acc = ffma(wl[n + k * kWmG], val(y[k]), acc);
-  }
-  for (; n + 15 * kWmG < N; n += 16 * kWmG) {
-    float y[16];
+    for (int k = 0; k < RND; ++k) {
+      const float w = wl[n + k * kWmG];
 #pragma unroll
-    for (int k = 0; k < 16; ++k) y[k] = col[(size_t)(n + k * kWmG) * HNu];
+      for (int v = 0; v < V; ++v) acc[v] = ffma(w, val(y[k][v], v), acc[v]);
+    }
+  }
+  constexpr int TAIL = 16 / V;
+  for (; n + (TAIL - 1) * kWmG < N; n += TAIL * kWmG) {
+    float y[TAIL][V];
+#pragma unroll
+    for (int k = 0; k < TAIL; ++k) {
+#pragma unroll
+      for (int v = 0; v < V; ++v) y[k][v] = Y0s[(size_t)(n + k * kWmG) * HNu + e[v]];
+    }
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int k = 0; k < 16; ++k) acc = ffma(wl[n + k * kWmG], val(y[k]), acc);
+    for (int k = 0; k < TAIL; ++k) {
+      const float w = wl[n + k * kWmG];
+#pragma unroll
+      for (int v = 0; v < V; ++v) acc[v] = ffma(w, val(y[k][v], v), acc[v]);
+    }
   }
-  for (; n < N; n += kWmG) acc = ffma(wl[n], val(col[(size_t)n * HNu]), acc);
-  red[g][j] = acc;
+  for (; n < N; n += kWmG) {
+    const float w = wl[n];
+#pragma unroll
+    for (int v = 0; v < V; ++v) acc[v] = ffma(w, val(Y0s[(size_t)n * HNu + e[v]], v), acc[v]);
+  }
+#pragma unroll
+  for (int v = 0; v < V; ++v) red[g][j * V + v] = acc[v];
   __syncthreads();
-  if (g != 0 || e_raw >= HNu) return;
-  if (ybar_keep) ybar_keep[e] = Ybar_i[e];
-  float tot = red[0][j];
+  // the 16 V outputs of the tile, one per thread of the first 16 V threads: the 64 partials of an output in group order
+  if ((int)threadIdx.x >= kWmE * V) return;
+  const int jo = threadIdx.x, eo = tile * (kWmE * V) + jo;
+  if (eo >= HNu) return;
+  if (ybar_keep) ybar_keep[eo] = Ybar_i[eo];
+  float tot = red[0][jo];
 #pragma unroll 8
-  for (int k = 1; k < kWmG; ++k) tot = tot + red[k][j];
+  for (int k = 1; k < kWmG; ++k) tot = tot + red[k][jo];
   float out = tot;
   if (literal) {
     const float sab = fsqrt(alpha_bar_i);
-    float Yi = Ybar_i[e] * sab;
+    float Yi = Ybar_i[eo] * sab;
     float t1 = 1.0f / (1.0f - alpha_bar_i);
     float t2 = sab * tot;
     float score = t1 * (-Yi + t2);
@@ -543,16 +587,28 @@ __device__ __forceinline__ void score_wmean_body(
     float Yim1 = (1.0f / fsqrt(alpha_i)) * (Yi + t3);
     out = Yim1 / fsqrt(alpha_bar_im1);
   }
-  Ybar_im1[e] = out;
+  Ybar_im1[eo] = out;
+}
+// XCD PINNING of the single-plan launches (round 5).  Workgroup i of a launch lands on XCD i mod 8.  A launch of T tiles is
+// therefore made 8 ceil(T / X) workgroups long, and only those with (i mod 8) < X work — on tile (i mod 8) ceil(T / X) + i / 8
+// — the others leave at once: the tiles of the launch then sit on X of the 8 XCDs, CONSECUTIVE tiles behind one L2, and a
+// line of a candidate row that two tiles share is fetched from HBM once per XCD instead of once per tile.  X (host side,
+// wmean_xcds): the fewest XCDs that give every tile a CU of its own (32 per XCD) and keep an XCD's share of the normals
+// within its 4 MB L2.  hopper512's ten tiles sat on eight XCDs and read 3.3x their algorithmic bytes, the metric's 54 tiles
+// 1.35x (seven tiles per XCD: 448 bytes of a row, plus a boundary line at each end).  -1: no such workgroup.
+__device__ __forceinline__ int pinned_tile(int i, int T, int X) {
+  const int c = i & 7, per = (T + X - 1) / X, t = c * per + (i >> 3);
+  return (c < X && (i >> 3) < per && t < T) ? t : -1;
 }
 static __global__ __launch_bounds__(kWmE * kWmG) void score_wmean_kernel(
     const float* __restrict__ rews, const float* __restrict__ lp_demo, int N, float rew_xref, float temp, int std_guard,
     float* __restrict__ weights_out, float* __restrict__ rew_mean_out, const float* __restrict__ Y0s, int HNu,
     const float* __restrict__ Ybar_i, float alpha_i, float alpha_bar_i, float alpha_bar_im1, int literal,
-    float* __restrict__ Ybar_im1, int lazy, float sigma, float* __restrict__ ybar_keep) {
+    float* __restrict__ Ybar_im1, int lazy, float sigma, float* __restrict__ ybar_keep, int T, int X) {
+  const int tile = pinned_tile(blockIdx.x, T, X);
+  if (tile < 0) return;  // (wave-uniform: the whole workgroup)
   score_wmean_body<48, true>(rews, lp_demo, N, rew_xref, temp, std_guard, weights_out, rew_mean_out, Y0s, HNu, Ybar_i, alpha_i,
-                   alpha_bar_i, alpha_bar_im1, literal, Ybar_im1, lazy, sigma, ybar_keep,
-                   xcd_tile(blockIdx.x, gridDim.x, 0), blockIdx.x == 0);
+                   alpha_bar_i, alpha_bar_im1, literal, Ybar_im1, lazy, sigma, ybar_keep, tile, tile == 0);
 }
 // SWEEPS (mbd_sweep_*): the same for P plans of one env in ONE launch — blockIdx.y is the plan, whose buffers sit at
 // fixed strides (in floats) from plan 0's; temperatures may differ per plan (run_mbd.py:42-64).  The body is the
@@ -561,8 +617,13 @@ struct ScoreBatch {
   long long rews, lp, weights, mean, cand, ybar_in, ybar_out, keep;
   const float* temps;  // [P], or nullptr: every plan at `temp`
 };
-// (eight wavefronts per SIMD — two workgroups per CU, 64 registers: the P x 54 workgroups of a sweep's step in one round)
-static __global__ __launch_bounds__(kWmE * kWmG, 8) void score_wmean_batch_kernel(
+// V = 1: eight wavefronts per SIMD — two workgroups per CU, 64 registers: the P x 54 workgroups of a sweep's step in one
+// round (rounds 3-4).  V = 2 (round 5, the default for sweeps: mbd_sweep.hip wmean_batch_v): P x 27 workgroups of 32 outputs
+// each, ONE per CU of plan k's XCD — they start together and stay together, a row segment is 128 bytes: the 2.0x of V = 1
+// (plan k's 54 tiles, two to a CU, drifting apart behind XCD k's 4 MB L2 while 3.5 MB of normals stream through it) is gone:
+// sweep8 28.2 MB per launch for 28.0 MB algorithmic, 11.3 us instead of 15.5 (profiles/r05_score_ab.txt).
+template <int V>
+static __global__ __launch_bounds__(kWmE * kWmG, V == 1 ? 8 : 4) void score_wmean_batch_kernel(
     const float* __restrict__ rews, const float* __restrict__ lp_demo, int N, float rew_xref, float temp, int std_guard,
     float* __restrict__ weights_out, float* __restrict__ rew_mean_out, const float* __restrict__ Y0s, int HNu,
     const float* __restrict__ Ybar_i, float alpha_i, float alpha_bar_i, float alpha_bar_im1, int literal,
@@ -579,7 +640,7 @@ static __global__ __launch_bounds__(kWmE * kWmG, 8) void score_wmean_batch_kerne
     k = c + 8 * (m / T);
     tile = m % T;
   }
-  score_wmean_body<32, false>(rews + k * sb.rews, lp_demo ? lp_demo + k * sb.lp : nullptr, N, rew_xref, sb.temps ? sb.temps[k] : temp,
+  score_wmean_body<32, false, V>(rews + k * sb.rews, lp_demo ? lp_demo + k * sb.lp : nullptr, N, rew_xref, sb.temps ? sb.temps[k] : temp,
                    std_guard, weights_out + k * sb.weights, rew_mean_out + k * sb.mean, Y0s + k * sb.cand, HNu,
                    Ybar_i + k * sb.ybar_in, alpha_i, alpha_bar_i, alpha_bar_im1, literal, Ybar_im1 + k * sb.ybar_out, lazy,
                    sigma, ybar_keep ? ybar_keep + k * sb.keep : nullptr, tile, tile == 0);

@@ -2,6 +2,26 @@
 // their candidates per step (mbd/scripts/run_mbd.py:17-64); MBD plans and the path-integral baselines.
 #include "mbd_internal.h"
 
+namespace {
+// outputs per thread of the sweeps' score + weighted mean launch (score_wmean_batch_kernel<V>): 2 — a workgroup owns 32 outputs,
+// 128 bytes of every candidate row, P x 27 workgroups for the humanoid.  Measured on sweep8 (profiles/r05_score_ab.txt; the
+// launch's algorithmic bytes are 28.0 MB): V = 1 15.5 us / 48.2 MB, V = 2 11.3 us / 28.2 MB, V = 4 22.0 us / 28.2 MB.
+// MBD_WMEAN_V = 1 / 2 / 4 forces it (A/B, tests; same bits whatever it is)
+int wmean_batch_v() {
+  const int v = lever("MBD_WMEAN_V");
+  return (v == 1 || v == 2 || v == 4) ? v : 2;
+}
+template <typename... Args>
+void launch_score_wmean_batch(int V, int HNu, int P, size_t lds, hipStream_t s, Args... args) {
+  using namespace mbd;
+  const dim3 block(kWmE * kWmG);
+  auto tiles = [&](int v) { return dim3((unsigned)((HNu + kWmE * v - 1) / (kWmE * v)), (unsigned)P); };
+  if (V == 1) hipLaunchKernelGGL(score_wmean_batch_kernel<1>, tiles(1), block, lds, s, args...);
+  else if (V == 2) hipLaunchKernelGGL(score_wmean_batch_kernel<2>, tiles(2), block, lds, s, args...);
+  else hipLaunchKernelGGL(score_wmean_batch_kernel<4>, tiles(4), block, lds, s, args...);
+}
+}  // namespace
+
 // ---- sweeps: P plans of one env in lockstep (mbd/scripts/run_mbd.py:17-64) ---------------------------------------
 struct mbd_sweep {
   mbd_env* env = nullptr;
@@ -204,10 +224,9 @@ static int sweep_run_path_integral(mbd_sweep* w, const uint32_t* keys, float* mu
       ScoreBatch sb;
       sb.rews = N; sb.lp = N; sb.weights = N; sb.mean = Nd - 1; sb.cand = (long long)per_plan;
       sb.ybar_in = mu_stride; sb.ybar_out = (long long)(Nd - 1) * HNu; sb.keep = 0; sb.temps = w->d_temps;
-      hipLaunchKernelGGL(score_wmean_batch_kernel, dim3((HNu + kWmE - 1) / kWmE, (unsigned)P), dim3(kWmE * kWmG),
-                         sizeof(float) * (size_t)N, s, w->d_rews, (const float*)nullptr, N, e->rew_xref, c.temp_sample, 0,
-                         w->d_weights, w->d_rewmeans + step, (const float*)w->d_Y0s, HNu, mu_in, 1.0f, 1.0f, 1.0f, 0, mu_out, 0,
-                         0.0f, (float*)nullptr, sb);
+      launch_score_wmean_batch(wmean_batch_v(), HNu, P, sizeof(float) * (size_t)N, s, w->d_rews, (const float*)nullptr, N, e->rew_xref,
+                               c.temp_sample, 0, w->d_weights, w->d_rewmeans + step, (const float*)w->d_Y0s, HNu, mu_in, 1.0f, 1.0f,
+                               1.0f, 0, mu_out, 0, 0.0f, (float*)nullptr, sb);
       if (c.update_method == 2) {
         hipLaunchKernelGGL(cma_spread_kernel, dim3((HNu + 63) / 64, (unsigned)P), b64, 0, s, (const float*)w->d_weights,
                            (const float*)w->d_Y0s, N, HNu, mu_in, w->d_spread, pb);
@@ -342,11 +361,10 @@ extern "C" int mbd_sweep_run(mbd_sweep* w, const uint32_t* keys, float* mu_0ts_o
       if (rc != MBD_OK) return rc;
     }
     sb.ybar_in = ybar_in_stride;
-    hipLaunchKernelGGL(score_wmean_batch_kernel, dim3((HNu + kWmE - 1) / kWmE, (unsigned)P), dim3(kWmE * kWmG),
-                       sizeof(float) * (size_t)N, s, w->d_rews, c.enable_demo ? w->d_lp : nullptr, N, e->rew_xref,
-                       c.temp_sample, 1, w->d_weights, w->d_rewmeans + step, w->d_eps[cur], HNu, ybar_in, w->alphas[i],
-                       w->alphas_bar[i], w->alphas_bar[i - 1], c.literal_score, w->d_mu + (size_t)step * HNu, 1,
-                       w->sigmas[i], (float*)nullptr, sb);
+    launch_score_wmean_batch(wmean_batch_v(), HNu, P, sizeof(float) * (size_t)N, s, w->d_rews, c.enable_demo ? w->d_lp : nullptr, N,
+                             e->rew_xref, c.temp_sample, 1, w->d_weights, w->d_rewmeans + step, w->d_eps[cur], HNu, ybar_in,
+                             w->alphas[i], w->alphas_bar[i], w->alphas_bar[i - 1], c.literal_score,
+                             w->d_mu + (size_t)step * HNu, 1, w->sigmas[i], (float*)nullptr, sb);
     HIP_TRY(hipGetLastError());
   }
   HIP_TRY(hipStreamSynchronize(s));

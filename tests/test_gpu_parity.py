@@ -1282,6 +1282,45 @@ def test_phase2_kernel_variants_and_shared_device_are_bit_identical(gpu, name, N
     other.close()
     assert np.array_equal(mu, mu0) and np.array_equal(rm, rm0) and rf == rf0 and np.array_equal(w, w0)
 
+@pytest.mark.parametrize("name,N,H", [("humanoidrun", 1024, 50), ("hopper", 333, 50), ("halfcheetah", 200, 17), ("car2d", 128, 30)])
+def test_score_launch_layouts_are_bit_identical(gpu, name, N, H, levers):
+    """Round 5: the single-plan score + weighted-mean launch is pinned to X of the 8 XCDs (MBD_WMEAN_XCDS; the library picks X
+    from the tile count and the candidates' bytes) and the sweeps' batch launch gives a thread V outputs (MBD_WMEAN_V; default 2).
+    Which workgroup computes which outputs never enters a value: whole plans and sweeps under every setting, bit for bit — odd
+    output counts (halfcheetah H=17: 102 outputs, a partial last tile at every V) included."""
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.mbd_planner import Args, Plan
+    from mbd_hip.scripts.run_mbd import run_concurrent
+    env = get_env(name)
+    args = Args(env_name=name, Nsample=N, Hsample=H, Ndiffuse=6, temp_sample=0.1, disable_recommended_params=True, not_render=True)
+    st, key = env.reset(gpu.prng_key(2)), gpu.prng_key(11)
+
+    def run():
+        p = Plan(env, args)
+        p.set_state0(st)
+        out = p.run(key)[:3]
+        p.close()
+        return out
+    mu0, rm0, rf0 = run()
+    for x in (1, 2, 4, 8):
+        levers(MBD_WMEAN_XCDS=x)
+        mu, rm, rf = run()
+        assert np.array_equal(mu, mu0) and np.array_equal(rm, rm0) and rf == rf0, x
+    levers(MBD_WMEAN_XCDS=-1)
+    if name == "car2d":
+        return
+    plans = [Args(seed=s, env_name=name, Nsample=min(N, 256), Hsample=H, Ndiffuse=5, temp_sample=0.1, disable_recommended_params=True,
+                  not_render=True) for s in range(8)]
+    base = None
+    for v in (2, 1, 4):
+        levers(MBD_WMEAN_V=v)
+        rews, mus, _ = run_concurrent(plans, batched=True)
+        if base is None:
+            base = (rews, mus)
+        assert np.array_equal(np.float32(rews), np.float32(base[0])) and all(np.array_equal(a, b) for a, b in zip(mus, base[1])), v
+    levers(MBD_WMEAN_V=-1)
+
+
 # ---- two candidates per lane (mbd_pk2.h) -----------------------------------------------------------------------------
 @pytest.mark.parametrize("name,B,H,sigma", [("humanoidrun", 96, 50, 0.6), ("humanoidrun", 1, 3, 0.3),
                                             ("humanoidrun", 37, 20, 0.9), ("humanoidtrack", 64, 50, 0.4),
