@@ -14,7 +14,7 @@ orc_mod.build()
 orc = orc_mod.Oracle("f32")
 first, count = int(sys.argv[1]), int(sys.argv[2])
 mode = sys.argv[3] if len(sys.argv) > 3 else "3d"
-bad = refused = touched = 0
+bad = refused = touched = blown = 0
 kinds = {}
 for seed in range(first, first + count):
     bits = 0
@@ -38,7 +38,11 @@ for seed in range(first, first + count):
     got = env.rollout(st, us).cpu().numpy()
     ref = orc.rollout(m.to_struct(), np.asarray(st.pipeline_state, np.float32), us)
     touched += int(np.abs(np.diff(ref, axis=1)).max() > 0.02)  # (a jump of the per-step reward: an impact)
-    if not np.array_equal(got, ref):
+    # (a model that the switches drive unstable — seed 151 of `spec`: friction as a velocity bound on links with two colliders,
+    # Jacobi-summed since round 5 — blows up in the checker and in the kernel alike: NaN at the same places counts as equal)
+    blown += int(not np.isfinite(ref).all())
+    if not np.array_equal(got, ref, equal_nan=True):
         bad += 1
-        print(seed, "MISMATCH max|d|", np.abs(got - ref).max(), "links", m.n_links)
-print(f"{mode} seeds {first}..{first + count - 1}: {bad} mismatches, {refused} refused, {touched} with an impact in the horizon")
+        print(seed, "MISMATCH max|d|", np.nanmax(np.abs(got - ref)), "links", m.n_links, "non-finite:", int((~np.isfinite(got)).sum()), int((~np.isfinite(ref)).sum()))
+print(f"{mode} seeds {first}..{first + count - 1}: {bad} mismatches, {refused} refused, {touched} with an impact in the horizon, "
+      f"{blown} non-finite in checker and kernel alike")
