@@ -84,10 +84,8 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   constexpr bool DPP = D0 != 0;
   constexpr int NSLOT = DPP ? (D1 != 0 ? 2 : 1) : kMaxChildren;
   rollout_progress(P);
-  if ((int)blockIdx.x >= P.roll_blocks) {  // the next step's normals, on CUs the rollout leaves idle (mbd_kernels.h)
-    noise_blocks(P);
-    return;
-  }
+  const int rblock = rollout_block(P);  // (noise workgroups and the idle ones of a pinned launch are done here: mbd_kernels.h)
+  if (rblock < 0) return;
   const mbd_model_t* __restrict__ M = P.model;
   const int lane = threadIdx.x & 63;
   const int base = lane & ~(LPS - 1);
@@ -99,7 +97,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   auto lane_of = [&](int link) { return base + (DPP ? (int)P.lane_tab[16 + link] : link); };
   const bool root_lane = link_ok && l == 0;
   constexpr int SPW = 64 / LPS;
-  const int wave_id = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+  const int wave_id = rblock * (blockDim.x >> 6) + (threadIdx.x >> 6);
   const int b_raw = wave_id * SPW + lane / LPS;
   const bool b_ok = b_raw < P.B;
   const int b = b_ok ? b_raw : P.B - 1;

@@ -1321,6 +1321,30 @@ def test_score_launch_layouts_are_bit_identical(gpu, name, N, H, levers):
     levers(MBD_WMEAN_V=-1)
 
 
+@pytest.mark.parametrize("name,B,H", [("hopper", 512, 20), ("halfcheetah", 200, 12), ("humanoidrun", 100, 10), ("cartpole", 64, 30), ("ant", 128, 8)])
+def test_rollout_launch_pinned_to_one_xcd_is_bit_identical(gpu, orc_omp, name, B, H, levers):
+    """Round 5: small rollout launches are made 8 x as long and only every 8th workgroup rolls out (they all land on one XCD; the
+    others carry the noise or leave): MBD_ROLL_PIN = 0 / 1 — rewards bit for bit the checker's either way, and a whole plan
+    (whose launches carry the next step's normals in the other workgroups) equal under both."""
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.mbd_planner import Args, Plan
+    env = get_env(name)
+    oe = _oenv(orc_omp, env)
+    st = env.reset(gpu.prng_key(1))
+    us = np.clip(np.random.default_rng(B).normal(size=(B, H, env.action_size)) * 0.5, -1.2, 1.2).astype(np.float32)
+    ref = oe.rollout(np.asarray(st.pipeline_state, np.float32), us)
+    outs = []
+    for pin in (0, 1):
+        levers(MBD_ROLL_PIN=pin)
+        assert np.array_equal(env.rollout(st, us).cpu().numpy(), ref), pin
+        p = Plan(env, Args(env_name=name, Nsample=B, Hsample=H, Ndiffuse=5, temp_sample=0.1, disable_recommended_params=True, not_render=True))
+        p.set_state0(st)
+        outs.append(p.run(gpu.prng_key(3))[:3])
+        p.close()
+    levers(MBD_ROLL_PIN=-1)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+
+
 # ---- two candidates per lane (mbd_pk2.h) -----------------------------------------------------------------------------
 @pytest.mark.parametrize("name,B,H,sigma", [("humanoidrun", 96, 50, 0.6), ("humanoidrun", 1, 3, 0.3),
                                             ("humanoidrun", 37, 20, 0.9), ("humanoidtrack", 64, 50, 0.4),
