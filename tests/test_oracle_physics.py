@@ -280,3 +280,27 @@ def test_physical_pendulum_period_and_energy(orc, tmp_path, planar):
     assert abs(period - T_ref) / T_ref < 0.01, (period, T_ref)
     first, last = np.abs(ang[: int(T_ref / dt)]).max(), np.abs(ang[-int(T_ref / dt):]).max()
     assert last <= first * 1.001 and last > 0.5 * first, (first, last)  # no energy gain; position-based damping is mild
+
+
+def test_dependency_depth_of_a_substep(orc):
+    """oracle/count_ops.cc carries, beside every value, the length of the dependency chain that produced it (round 5: the latency
+    floor of a substep, measured).  The counting build computes the same values as the plain one; the depth grows by the same
+    amount every substep (the recurrence's critical path), is the same for every link (the tree couples them within a substep),
+    and is several times smaller than the operations per link — the width a wider layout could harvest at best."""
+    from conftest import load_model
+    from oracle import oracle as orc_mod
+    for name, lo, hi in (("humanoidrun", 150, 220), ("hopper", 90, 130)):
+        m = load_model(name)
+        ms = m.to_struct()
+        s = orc.forward(ms, m.init_q, np.zeros(m.qd_size(), np.float32))
+        a = np.full(m.act_size(), 0.3, np.float32)
+        for _ in range(12):
+            s, _ = orc.env_step(ms, s, a)
+        d = orc_mod.depth_substeps(ms, s, a, 10).astype(np.int64)
+        growth = np.diff(d[:, -1])
+        assert (growth[4:] == growth[-1]).all() and lo <= growth[-1] <= hi, (name, growth)
+        assert (d[-1, :-1] - d[-2, :-1] == growth[-1]).all()
+        counts, out = orc_mod.count_substep(ms, s, a)
+        assert np.array_equal(out.reshape(-1), orc.substep(ms, s, a).reshape(-1))   # (counting does not change a value)
+        ops = counts["add"] + counts["mul"] + counts["fma"] + counts["div"] + counts["sqrt"] + counts["cmp"]
+        assert ops / m.n_links > 2.0 * growth[-1]
