@@ -12,7 +12,8 @@ import json,sys
 d=json.loads(sys.stdin.read())
 r=lambda v: round(v,3) if isinstance(v,float) else v
 print('value', r(d['value']), '[', r(d['value_min']), r(d['value_max']), ']', d['unit'][:40], '| ms/step', r(d['ms_per_step']), '| N/GPU', d['config']['N_per_gpu'])
-print('collective', d['config']['collective'][:70])
+print('collective', d['config']['collective'][:70], '| rccl_world', d.get('rccl_world'), '|', d.get('dist_backend'))
+print('scaling_expectation.strong:', (d.get('scaling_expectation') or {}).get('strong', '')[:110])
 print('phase_ms', {k:r(v) for k,v in (d.get('phase_ms') or {}).items()})
 print('other_collective', {k:r(v) for k,v in d.get('other_collective',{}).items() if k!='note'})
 print('other_scaling', {k:r(v) for k,v in d.get('other_scaling',{}).items()})
