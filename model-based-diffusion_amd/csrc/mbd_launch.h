@@ -49,6 +49,8 @@ hipError_t launch_rollout_hot3d(int which, int rk, int nfr, int device, dim3 gri
 // switches (MBD_SPEC_FLAGS): the SPEC instantiation (16 lanes, shuffle exchange) reads them at run time
 hipError_t launch_rollout_planar(int lps, int dpp_family, int max_col, int fl, int rk, int nfr, bool no_fl, bool spec, int device,
                                  dim3 grid, dim3 block, size_t lds, hipStream_t stream, const RolloutParams& P);
+// whether an early-out instantiation (RolloutParams::cpw) exists for such a model with its switches as compile-time constants
+bool planar_has_early_out(int lps, int dpp_family, int max_col, int fl, int rk, int nfr);
 // fam: 0 the humanoid family, 1 ant (mbd_pk2.h)
 hipError_t launch_rollout_pk2(int fam, int maxcol, int rk, int nfr, int wpe, int device, dim3 grid, dim3 block, size_t lds,
                               hipStream_t stream, const RolloutParams& P);

@@ -12,6 +12,8 @@
 // flag of the MODEL and shared with the CPU checker, which the tests hold it to bit for bit.
 #pragma once
 
+#include <type_traits>
+
 #include "mbd_kernels.h"
 
 namespace mbd {
@@ -48,15 +50,29 @@ __device__ __forceinline__ void pl_rot2(PCs2 a, f2 x, f2 z, f2& ox, f2& oz) {
 __device__ __forceinline__ f2 pl_cross2(f2 rx, f2 rz, f2 fx, f2 fz) { return fma2(rz, fx, -(rx * fz)); }
 __device__ __forceinline__ f2 bc2(float a) { return mk2(a, a); }
 
-template <bool NORMALIZE>
-__device__ __forceinline__ void pl_qupdate(float& w, float& y, float dth) {
+// QM: how the renormalisation's rare exact side (|n2 - 1| > 0.05: a link turning by more than 0.45 rad in ONE substep) is handled.
+//   0  a branch where it happens (v_cmp -> s_and_saveexec -> s_cbranch: ~40 cycles of compare-to-branch latency for a lone
+//      wavefront per SIMD even when never taken, tools/probes/probe_branch.hip)
+//   1  SPECULATIVE (the early-out instantiations): the series is used unconditionally and the largest |n2 - 1| seen is kept in
+//      `worst` (one v_max); the caller tests it once per CONTROL step and, when it ever exceeded the bound, re-runs that control
+//      step from its saved start with QM = 2
+//   2  both sides computed, the exact one selected where it applies — the values of QM = 0, branch-free
+template <bool NORMALIZE, int QM = 0>
+__device__ __forceinline__ void pl_qupdate(float& w, float& y, float dth, float& worst) {
   const float h = 0.5f * dth;
   float nw = ffma(-h, y, w), ny = ffma(h, w, y);
   if constexpr (NORMALIZE) {
     const float n2 = ffma(nw, nw, ny * ny);
     const float e = n2 - 1.0f;
     float inv = ffma(ffma(ffma(ffma(0.2734375f, e, -0.3125f), e, 0.375f), e, -0.5f), e, 1.0f);
-    if (__builtin_expect(fabs_(e) > 0.05f, 0)) inv = 1.0f / fsqrt(n2);
+    if constexpr (QM == 1) {
+      worst = fmax_(worst, fabs_(e));
+    } else if constexpr (QM == 2) {
+      const float exact = 1.0f / fsqrt(n2);
+      inv = fabs_(e) > 0.05f ? exact : inv;
+    } else {
+      if (__builtin_expect(fabs_(e) > 0.05f, 0)) inv = 1.0f / fsqrt(n2);
+    }
     nw = nw * inv; ny = ny * inv;
   }
   w = nw; y = ny;
@@ -77,10 +93,20 @@ __device__ __forceinline__ void pl_qupdate(float& w, float& y, float dth) {
 // friction_vel_bound, restitution_min — DESIGN.md §9) are read at run time and honoured as the checker's planar
 // restatement states them; one general instantiation is built with it (models carrying such a bit run there), every other one
 // compiles the default specification in.
-template <int LPS, int MAXCOL, int D0 = 0, int D1 = 0, int FL = -1, int RK = -1, int NFR = 0, bool SPEC = false>
+// EO (round 6): the launch puts P.cpw < 64 / LPS candidates on a wavefront (launches that would leave SIMDs idle anyway:
+// hopper512's 32 wavefronts become 512, one candidate each) and the substep takes a WAVE-UNIFORM EARLY-OUT around the
+// contact code: once the penetrations of stage (4) are known and no lane has a sphere below the plane, the rest of stage
+// (4) and all of stage (6) are exact no-ops (every effect of theirs sits behind a select on `active`), so the wavefront
+// branches around them — a single hopper candidate is airborne in 87-90 % of its substeps, a halfcheetah in 43-57 %,
+// which 16 (8) candidates sharing a wavefront never are together.  The lanes of the groups beyond P.cpw REPEAT the
+// wavefront's candidates (group g runs candidate g mod cpw, stores nothing), so the predicate is that of the cpw
+// candidates alone.  Results are bit-identical for every cpw (the skipped path keeps the stage's two additions of +0 and
+// its quaternion renormalisation).
+template <int LPS, int MAXCOL, int D0 = 0, int D1 = 0, int FL = -1, int RK = -1, int NFR = 0, bool SPEC = false, bool EO = false>
 __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   static_assert(NFR % 2 == 0, "NFR: two iterations of NFR / 2");
   static_assert(!SPEC || (D0 == 0 && FL < 0), "SPEC: the general shuffle-exchange instantiation");
+  static_assert(!EO || (MAXCOL == 2 && !SPEC), "EO: the packed two-collider contact stages");
   constexpr bool DPP = D0 != 0;
   constexpr int NSLOT = DPP ? (D1 != 0 ? 2 : 1) : kMaxChildren;
   rollout_progress(P);
@@ -98,9 +124,14 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   const bool root_lane = link_ok && l == 0;
   constexpr int SPW = 64 / LPS;
   const int wave_id = rblock * (blockDim.x >> 6) + (threadIdx.x >> 6);
-  const int b_raw = wave_id * SPW + lane / LPS;
-  const bool b_ok = b_raw < P.B;
-  const int b = b_ok ? b_raw : P.B - 1;
+  // candidates per wavefront: SPW, or (EO) the launch's choice P.cpw, a power of two below it
+  const int cpw = EO ? P.cpw : SPW;
+  const int grp = lane / LPS;
+  const int b_first = wave_id * cpw;
+  const int b_raw = b_first + (EO ? (grp & (cpw - 1)) : grp);
+  const bool b_ok = b_raw < P.B && grp < cpw;
+  // (lanes without a candidate of their own repeat one of the wavefront's: the tail of the launch, the groups beyond cpw)
+  const int b = b_raw < P.B ? b_raw : (EO && b_first < P.B ? b_first : P.B - 1);
   const int H = P.H, Nu = M->n_act, nfr = NFR > 0 ? NFR : M->n_frames;
 
   // ---- per-lane model constants (padding lanes: everything that scales a contribution is zero) ------------
@@ -186,6 +217,9 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         ++nc;
       }
   }
+  // (EO) the radii with -inf where the lane has no such collider: its "penetration" in the early-out test is then -inf
+  const f2 radb2 = mk2((MAXCOL > 0 && col_has[0]) ? col_rad[0] : -__builtin_inff(),
+                       (MAXCOL > 1 && col_has[MAXCOL > 1 ? 1 : 0]) ? col_rad[MAXCOL > 1 ? 1 : 0] : -__builtin_inff());
   const float comx = M->com[l][0], comz = M->com[l][2];
   const float dt = M->dt, inv_dt = 1.0f / M->dt, vel_fac = M->vel_fac, ang_fac = M->ang_fac;
   const float two_inv_dt = 2.0f * inv_dt;
@@ -295,7 +329,9 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
     // One substep; the loop below runs it four at a time: its back edge is a TAKEN branch, which costs a lone wavefront
     // 30-60 cycles of instruction-buffer refill — 3 % of a 350-instruction substep (n_frames is 20 / 16 / 4 for the
     // built-in planar models: the remainder loop never runs for them).
-    auto substep = [&]() __attribute__((always_inline)) {
+    float q_worst = 0.0f;  // (EO) the largest |n2 - 1| a renormalisation of this control step saw (pl_qupdate, QM = 1)
+    auto substep_qm = [&](auto qm_tag) __attribute__((always_inline)) {
+      constexpr int QM = decltype(qm_tag)::value;
       // ---- (1) joints.acceleration_update ----------------------------------------------------------------
       float Ppx = from_parent(px), Ppz = from_parent(pz), Pw = from_parent(qw) + wpar, Py = from_parent(qy);
       const float Pvx = from_parent(vx), Pvz = from_parent(vz), Pom = from_parent(om);
@@ -342,7 +378,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       const float pxp = px, pzp = pz, qwp = qw, qyp = qy;
       px = ffma(vx, dt, px);
       pz = ffma(vz, dt, pz);
-      pl_qupdate<true>(qw, qy, om * dt);
+      pl_qupdate<true, QM>(qw, qy, om * dt, q_worst);
       // ---- (3) joints.position_update (Jacobi) ---------------------------------------------------------------
       Ppx = from_parent(px); Ppz = from_parent(pz); Pw = from_parent(qw) + wpar; Py = from_parent(qy);
       float dcx, dcz, dcth, dpx, dpz, dpth;
@@ -398,48 +434,119 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       {
         const float ax = add_children(dcx, dpx), az = add_children(dcz, dpz), ath = add_children(dcth, dpth);
         px = px + ax; pz = pz + az;
-        pl_qupdate<false>(qw, qy, ath);  // renormalised at the end of stage (4)
+        pl_qupdate<false>(qw, qy, ath, q_worst);  // renormalised at the end of stage (4)
       }
       // ---- (4) sphere-plane contacts + collisions.resolve_position -----------------------------------------
       float cposx[MAXCOL > 0 ? MAXCOL : 1], cposz[MAXCOL > 0 ? MAXCOL : 1], cdlam[MAXCOL > 0 ? MAXCOL : 1];
       bool cact[MAXCOL > 0 ? MAXCOL : 1];
+      float vz_old, om_old;
+      // ---- (5) integrator.project_xd ------------------------------------------------------------------------
+      auto project_xd = [&]() __attribute__((always_inline)) {
+        vz_old = vz; om_old = om;
+        vx = (px - pxp) * inv_dt;
+        vz = (pz - pzp) * inv_dt;
+        const float dqw = ffma(qw, qwp, qy * qyp);
+        const float dqy = ffma(qy, qwp, -(qw * qyp));
+        om = dqy * __builtin_copysignf(two_inv_dt, dqw);
+      };
+      // ---- (6) collisions.resolve_velocity (Jacobi per link), both colliders of the link as one packed pair ----
+      // (Jacobi makes them independent, like stage (4): every contact of the link computes its impulse from the velocities
+      // stage (5) left; the changes are added in collider order)
+      auto resolve_velocity_pair = [&]() __attribute__((always_inline)) {
+        const f2 rcx = mk2(cposx[0], cposx[1]) - bc2(px), rcz = mk2(cposz[0], cposz[1]) - bc2(pz);
+        const f2 vptx = fma2(bc2(om), rcz, bc2(vx)), vptz = fma2(bc2(-om), rcx, bc2(vz));
+        f2 vn_prev = bc2(0.0f);
+        if (FL >= 0 ? (FL & 4) != 0 : elast != 0.0f) vn_prev = fma2(bc2(-om_old), rcx, bc2(vz_old));  // (wave-uniform; with e = 0 the term is exactly 0)
+        const f2 vtn = __builtin_elementwise_abs(vptx);
+        const f2 icn = rcx * bc2(iy_c);
+        const f2 wn = fma2(icn, rcx, bc2(im_c));
+        const f2 wt = fma2(rcz, rcz * bc2(iy_c), bc2(im_c));
+        const f2 rest = bc2(-elast) * vn_prev;
+        const f2 dvn = mk2(fmax_(rest.x, 0.0f), fmax_(rest.y, 0.0f)) - vptz;
+        const f2 jt_max = (bc2(mu) * mk2(cdlam[0], cdlam[1])) * bc2(inv_dt);
+        const f2 jw = jt_max * wt;
+        const f2 dvt = mk2(fmin_(jw.x, vtn.x), fmin_(jw.y, vtn.y));
+        f2 q_n, q_t;
+        div2x2_sp_(dvn, wn, dvt, wt, q_n, q_t);
+        const f2 Pix = mk2(-__builtin_copysignf(q_t.x, vptx.x), -__builtin_copysignf(q_t.y, vptx.y)), Piz = q_n;  // friction opposes the slip
+        const f2 dom = pl_cross2(rcx, rcz, Pix, Piz) * bc2(iy_c);
+        const float nvx0 = ffma(im_c, Pix.x, vx), nvz0 = ffma(im_c, Piz.x, vz), nom0 = om + dom.x;
+        vx = cact[0] ? nvx0 : vx; vz = cact[0] ? nvz0 : vz; om = cact[0] ? nom0 : om;
+        float nvx1 = ffma(im_c, Pix.y, vx), nvz1 = ffma(im_c, Piz.y, vz), nom1 = om + dom.y;
+        // (EO: the three stay SELECTS — left alone the compiler sinks them under an EXEC mask, and one divergent region anywhere
+        // makes it linearise the early-out's uniform if / else through flag registers: a second branch on the common path)
+        if constexpr (EO) asm volatile("" : "+v"(nvx1), "+v"(nvz1), "+v"(nom1));
+        vx = cact[1] ? nvx1 : vx; vz = cact[1] ? nvz1 : vz; om = cact[1] ? nom1 : om;
+      };
       {
         float cdx = 0.0f, cdz = 0.0f, cdth = 0.0f;
         if constexpr (MAXCOL == 2) {
           // both colliders of the link as one packed pair (the solve is Jacobi: each sees the pose of the stage's
           // start); their corrections are then added in collider order
-          const PCs a = pl_cs(qw, qy), ap = pl_cs(qwp, qyp);
+          const PCs a = pl_cs(qw, qy);
           const f2 cx2 = mk2(colx[0], colx[1]), cz2 = mk2(colz[0], colz[1]), rad2 = mk2(col_rad[0], col_rad[1]);
           const f2 offx = fma2(bc2(a.s), cz2, bc2(a.c) * cx2), offz = fma2(bc2(-a.s), cx2, bc2(a.c) * cz2);
           const f2 ctrx = bc2(px) + offx, ctrz = bc2(pz) + offz;
           const f2 pen = rad2 - ctrz;
           const bool act0 = col_has[0] && pen.x > 0.0f, act1 = col_has[1] && pen.y > 0.0f;
-          const f2 h = fma2(bc2(-0.5f), pen, rad2);
-          const f2 posx = ctrx, posz = ctrz - h;
-          const f2 rcx = offx, rcz = offz - h;
-          const f2 icn = rcx * bc2(iy_c);
-          const f2 wn = fma2(icn, rcx, bc2(im_c));
-          const f2 d = -h;
-          const f2 rlx = fma2(bc2(-a.s), d, cx2), rlz = fma2(bc2(a.c), d, cz2);
-          const f2 pprevx = bc2(pxp) + fma2(bc2(ap.s), rlz, bc2(ap.c) * rlx);
-          const f2 ddx = posx - pprevx;
-          // static friction: the tangent is the x axis, |d|^2 / (d.W d) of the 3-D form is 1 / (im + rcz^2 iy)
-          const f2 wt = fma2(rcz, rcz * bc2(iy_c), bc2(im_c));
-          f2 q_n, q_g;
-          div2x2_(pen, wn, bc2(1.0f), wt, q_n, q_g);
-          const f2 dlam = q_n * bc2(coll_scale), sx = q_g * ddx;
-          const f2 lim = bc2(mu) * dlam;
-          const f2 lhs = sx * sx, rhs = lim * lim;
-          const f2 Pix = mk2(lhs.x < rhs.x ? -sx.x : 0.0f, lhs.y < rhs.y ? -sx.y : 0.0f), Piz = dlam;
-          const f2 dth = pl_cross2(rcx, rcz, Pix, Piz) * bc2(iy_c);
-          cdx = act0 ? ffma(im_c, Pix.x, cdx) : cdx;
-          cdz = act0 ? ffma(im_c, Piz.x, cdz) : cdz;
-          cdth = act0 ? cdth + dth.x : cdth;
-          cdx = act1 ? ffma(im_c, Pix.y, cdx) : cdx;
-          cdz = act1 ? ffma(im_c, Piz.y, cdz) : cdz;
-          cdth = act1 ? cdth + dth.y : cdth;
-          cposx[0] = posx.x; cposx[1] = posx.y; cposz[0] = posz.x; cposz[1] = posz.y;
-          cdlam[0] = dlam.x; cdlam[1] = dlam.y; cact[0] = act0; cact[1] = act1;
+          // the rest of the stage: everything it changes sits behind act0 / act1
+          auto resolve_position_pair = [&]() __attribute__((always_inline)) {
+            const PCs ap = pl_cs(qwp, qyp);
+            const f2 h = fma2(bc2(-0.5f), pen, rad2);
+            const f2 posx = ctrx, posz = ctrz - h;
+            const f2 rcx = offx, rcz = offz - h;
+            const f2 icn = rcx * bc2(iy_c);
+            const f2 wn = fma2(icn, rcx, bc2(im_c));
+            const f2 d = -h;
+            const f2 rlx = fma2(bc2(-a.s), d, cx2), rlz = fma2(bc2(a.c), d, cz2);
+            const f2 pprevx = bc2(pxp) + fma2(bc2(ap.s), rlz, bc2(ap.c) * rlx);
+            const f2 ddx = posx - pprevx;
+            // static friction: the tangent is the x axis, |d|^2 / (d.W d) of the 3-D form is 1 / (im + rcz^2 iy)
+            const f2 wt = fma2(rcz, rcz * bc2(iy_c), bc2(im_c));
+            f2 q_n, q_g;
+            div2x2_(pen, wn, bc2(1.0f), wt, q_n, q_g);
+            const f2 dlam = q_n * bc2(coll_scale), sx = q_g * ddx;
+            const f2 lim = bc2(mu) * dlam;
+            const f2 lhs = sx * sx, rhs = lim * lim;
+            const f2 Pix = mk2(lhs.x < rhs.x ? -sx.x : 0.0f, lhs.y < rhs.y ? -sx.y : 0.0f), Piz = dlam;
+            const f2 dth = pl_cross2(rcx, rcz, Pix, Piz) * bc2(iy_c);
+            cdx = act0 ? ffma(im_c, Pix.x, cdx) : cdx;
+            cdz = act0 ? ffma(im_c, Piz.x, cdz) : cdz;
+            cdth = act0 ? cdth + dth.x : cdth;
+            cdx = act1 ? ffma(im_c, Pix.y, cdx) : cdx;
+            cdz = act1 ? ffma(im_c, Piz.y, cdz) : cdz;
+            cdth = act1 ? cdth + dth.y : cdth;
+            cposx[0] = posx.x; cposx[1] = posx.y; cposz[0] = posz.x; cposz[1] = posz.y;
+            cdlam[0] = dlam.x; cdlam[1] = dlam.y; cact[0] = act0; cact[1] = act1;
+          };
+          if constexpr (EO) {
+            // WAVE-UNIFORM early-out: no sphere of any lane is below the plane.  What remains of stages (4) - (6) then:
+            // the corrections stay (+0, +0, 0) — added and renormalised as always — stage (5), and a stage (6) whose every
+            // select keeps the old value.
+            // The test costs a lone wavefront its compare-to-branch latency (~40 cycles: tools/probes/probe_branch.hip), so
+            // (a) it is ONE compare into vcc — the larger of the two penetrations, with -inf radii on the lanes that lack a
+            // collider: no scalar mask arithmetic — and (b) the common side's pose update is computed between the compare
+            // and the branch, where it is free (the side that has a contact discards it).
+            const f2 penb = radb2 - ctrz;
+            const bool touching = __builtin_amdgcn_fcmpf(fmax_(penb.x, penb.y), 0.0f, 2 /* ogt */) != 0ull;
+            __builtin_amdgcn_sched_barrier(0);
+            float fpx = px + cdx, fpz = pz + cdz, fqw = qw, fqy = qy;
+            pl_qupdate<true, QM>(fqw, fqy, cdth, q_worst);
+            asm volatile("" : "+v"(fpx), "+v"(fpz), "+v"(fqw), "+v"(fqy));  // (computed HERE: not sunk behind the branch)
+            __builtin_amdgcn_sched_barrier(0);
+            if (__builtin_expect(!touching, 1)) {
+              px = fpx; pz = fpz; qw = fqw; qy = fqy;
+              project_xd();
+            } else {
+              resolve_position_pair();
+              px = px + cdx; pz = pz + cdz;
+              pl_qupdate<true, QM>(qw, qy, cdth, q_worst);
+              project_xd();
+              resolve_velocity_pair();
+            }
+          } else {
+            resolve_position_pair();
+          }
         } else         if constexpr (MAXCOL > 0) {
           const PCs a = pl_cs(qw, qy), ap = pl_cs(qwp, qyp);
 #pragma unroll
@@ -479,44 +586,19 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
             cdx = n_act >= 2 ? cdx * inv_n : cdx; cdz = n_act >= 2 ? cdz * inv_n : cdz; cdth = n_act >= 2 ? cdth * inv_n : cdth;
           }
         }
-        px = px + cdx; pz = pz + cdz;
-        pl_qupdate<true>(qw, qy, cdth);
+        if constexpr (!EO) {
+          px = px + cdx; pz = pz + cdz;
+          pl_qupdate<true, QM>(qw, qy, cdth, q_worst);
+        }
       }
-      // ---- (5) integrator.project_xd -----------------------------------------------------------------------
-      const float vz_old = vz, om_old = om;
-      vx = (px - pxp) * inv_dt;
-      vz = (pz - pzp) * inv_dt;
-      {
-        const float dqw = ffma(qw, qwp, qy * qyp);
-        const float dqy = ffma(qy, qwp, -(qw * qyp));
-        om = dqy * __builtin_copysignf(two_inv_dt, dqw);
-      }
+      if constexpr (!EO) project_xd();
       // ---- (6) collisions.resolve_velocity (Jacobi per link) ---------------------------------------------------
       // every contact of the link computes its impulse from the velocities stage (5) left; the changes are added in collider
       // order (SPEC, contact6_gauss_seidel: one after the other, each from the running values)
-      if constexpr (MAXCOL == 2 && !SPEC) {
-        // both colliders of the link as one packed pair (Jacobi makes them independent), like stage (4)
-        const f2 rcx = mk2(cposx[0], cposx[1]) - bc2(px), rcz = mk2(cposz[0], cposz[1]) - bc2(pz);
-        const f2 vptx = fma2(bc2(om), rcz, bc2(vx)), vptz = fma2(bc2(-om), rcx, bc2(vz));
-        f2 vn_prev = bc2(0.0f);
-        if (FL >= 0 ? (FL & 4) != 0 : elast != 0.0f) vn_prev = fma2(bc2(-om_old), rcx, bc2(vz_old));  // (wave-uniform; with e = 0 the term is exactly 0)
-        const f2 vtn = __builtin_elementwise_abs(vptx);
-        const f2 icn = rcx * bc2(iy_c);
-        const f2 wn = fma2(icn, rcx, bc2(im_c));
-        const f2 wt = fma2(rcz, rcz * bc2(iy_c), bc2(im_c));
-        const f2 rest = bc2(-elast) * vn_prev;
-        const f2 dvn = mk2(fmax_(rest.x, 0.0f), fmax_(rest.y, 0.0f)) - vptz;
-        const f2 jt_max = (bc2(mu) * mk2(cdlam[0], cdlam[1])) * bc2(inv_dt);
-        const f2 jw = jt_max * wt;
-        const f2 dvt = mk2(fmin_(jw.x, vtn.x), fmin_(jw.y, vtn.y));
-        f2 q_n, q_t;
-        div2x2_sp_(dvn, wn, dvt, wt, q_n, q_t);
-        const f2 Pix = mk2(-__builtin_copysignf(q_t.x, vptx.x), -__builtin_copysignf(q_t.y, vptx.y)), Piz = q_n;  // friction opposes the slip
-        const f2 dom = pl_cross2(rcx, rcz, Pix, Piz) * bc2(iy_c);
-        const float nvx0 = ffma(im_c, Pix.x, vx), nvz0 = ffma(im_c, Piz.x, vz), nom0 = om + dom.x;
-        vx = cact[0] ? nvx0 : vx; vz = cact[0] ? nvz0 : vz; om = cact[0] ? nom0 : om;
-        const float nvx1 = ffma(im_c, Pix.y, vx), nvz1 = ffma(im_c, Piz.y, vz), nom1 = om + dom.y;
-        vx = cact[1] ? nvx1 : vx; vz = cact[1] ? nvz1 : vz; om = cact[1] ? nom1 : om;
+      if constexpr (EO) {
+        // (done above, on the path that had a contact)
+      } else if constexpr (MAXCOL == 2 && !SPEC) {
+        resolve_velocity_pair();
       } else if constexpr (MAXCOL > 0) {
         const float vx6 = vx, vz6 = vz, om6 = om;  // what every contact of the link sees
 #pragma unroll
@@ -554,6 +636,9 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         }
       }
     };
+    auto substep = [&]() __attribute__((always_inline)) { substep_qm(std::integral_constant<int, EO ? 1 : 0>{}); };
+    // (EO) the control step's start, for the rare re-run with the exact renormalisation
+    const float s_px = px, s_pz = pz, s_qw = qw, s_qy = qy, s_vx = vx, s_vz = vz, s_om = om;
     {
       phase_pad<mbd_pad_planar(LPS, MAXCOL, D0, D1, FL, RK, NFR)>();  // (code placement: tools/tune_phase.py)
       int fr = 0;
@@ -563,7 +648,15 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         for (; fr + 3 < nfr; fr += 4) { substep(); substep(); substep(); substep(); }
         for (; fr < nfr; ++fr) substep();
       }
-    }  // substeps
+    }
+    if constexpr (EO) {
+      // some renormalisation of this control step left the series' range (wave-uniform test; NaN compares false, like the
+      // branch it replaces): the control step again from its start, every renormalisation with its exact side selected
+      if (__builtin_expect(__builtin_amdgcn_fcmpf(q_worst, 0.05f, 2 /* ogt */) != 0ull, 0)) {
+        px = s_px; pz = s_pz; qw = s_qw; qy = s_qy; vx = s_vx; vz = s_vz; om = s_om;
+        for (int fr = 0; fr < nfr; ++fr) substep_qm(std::integral_constant<int, 2>{});
+      }
+    }
 
     // ---- reward ------------------------------------------------------------------------------------------------
     float o1x, o1z;

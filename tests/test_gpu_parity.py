@@ -1345,6 +1345,49 @@ def test_rollout_launch_pinned_to_one_xcd_is_bit_identical(gpu, orc_omp, name, B
     assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
 
 
+@pytest.mark.parametrize("name,B,H", [("hopper", 77, 50), ("hopper", 512, 10), ("halfcheetah", 61, 50), ("halfcheetah", 256, 16),
+                                      ("walker2d", 45, 50)])
+def test_candidates_per_wavefront_and_contact_early_out_are_bit_identical(gpu, orc_omp, name, B, H, levers):
+    """Round 6: launches that would leave SIMDs idle put fewer candidates on a wavefront (RolloutParams::cpw) and take a
+    wave-uniform early-out around the contact code of a substep in which no sphere of the wavefront is below the plane
+    (mbd_planar.h, EO).  MBD_CPW = 0 (the filled wavefronts of rounds 1-5) / 1 / 2 / 4 / 8 / unset (the library's choice): rewards bit
+    for bit the checker's under every value (ragged B: the last wavefront repeats candidates), and a whole plan equal under all."""
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.mbd_planner import Args, Plan
+    env = get_env(name)
+    oe = _oenv(orc_omp, env)
+    st = env.reset(gpu.prng_key(2))
+    us = np.clip(np.random.default_rng(B + H).normal(size=(B, H, env.action_size)) * 0.6, -1.2, 1.2).astype(np.float32)
+    ref = oe.rollout(np.asarray(st.pipeline_state, np.float32), us)
+    outs = []
+    for cpw in (0, 1, 2, 4, 8, -1):
+        levers(MBD_CPW=cpw)
+        assert np.array_equal(env.rollout(st, us).cpu().numpy(), ref), cpw
+        p = Plan(env, Args(env_name=name, Nsample=B, Hsample=min(H, 12), Ndiffuse=5, temp_sample=0.1, disable_recommended_params=True, not_render=True))
+        p.set_state0(st)
+        outs.append(p.run(gpu.prng_key(3))[:3])
+        p.close()
+    levers(MBD_CPW=-1)
+    for o in outs[1:]:
+        assert np.array_equal(outs[0][0], o[0]) and np.array_equal(outs[0][1], o[1]) and outs[0][2] == o[2]
+
+
+@pytest.mark.parametrize("name,N,H,Nd,cpw", [("hopper", 96, 20, 6, 0), ("hopper", 96, 20, 6, 2), ("halfcheetah", 50, 16, 5, 0), ("halfcheetah", 50, 16, 5, 1)])
+def test_sweep_under_every_candidates_per_wavefront(gpu, name, N, H, Nd, cpw, levers):
+    """... and a sweep (several plans in one launch: candidate b belongs to plan b / N) equals its plans run alone whatever the lever says."""
+    from mbd_hip.planners.mbd_planner import Args, run_diffusion
+    from mbd_hip.scripts.run_mbd import run_concurrent
+    plans = [Args(seed=s, env_name=name, Nsample=N, Hsample=H, Ndiffuse=Nd, temp_sample=0.1, disable_recommended_params=True, not_render=True)
+             for s in range(3)]
+    levers(MBD_CPW=cpw)
+    rews, mus, _ = run_concurrent(plans, batched=True)
+    levers(MBD_CPW=-1)
+    for a, r, mu in zip(plans, rews, mus):
+        r_seq, det = run_diffusion(a, return_details=True)
+        assert np.array_equal(mu, det["mu_0ts"]), (name, a.seed)
+        assert np.float32(r) == np.float32(r_seq)
+
+
 # ---- two candidates per lane (mbd_pk2.h) -----------------------------------------------------------------------------
 @pytest.mark.parametrize("name,B,H,sigma", [("humanoidrun", 96, 50, 0.6), ("humanoidrun", 1, 3, 0.3),
                                             ("humanoidrun", 37, 20, 0.9), ("humanoidtrack", 64, 50, 0.4),
