@@ -108,6 +108,13 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   static_assert(!SPEC || (D0 == 0 && FL < 0), "SPEC: the general shuffle-exchange instantiation");
   static_assert(!EO || (MAXCOL == 2 && !SPEC), "EO: the packed two-collider contact stages");
   constexpr bool DPP = D0 != 0;
+  // the renormalisations' rare exact side is SPECULATED away (pl_qupdate QM = 1: no compare-to-branch latency in the substep;
+  // a control step in which it would have been taken is re-run).  MBD_PLANAR_NO_SPECULATE: the branches of rounds 1-5 (A/B).
+#ifdef MBD_PLANAR_NO_SPECULATE
+  constexpr bool SPECULATE = EO;
+#else
+  constexpr bool SPECULATE = true;
+#endif
   constexpr int NSLOT = DPP ? (D1 != 0 ? 2 : 1) : kMaxChildren;
   rollout_progress(P);
   const int rblock = rollout_block(P);  // (noise workgroups and the idle ones of a pinned launch are done here: mbd_kernels.h)
@@ -329,7 +336,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
     // One substep; the loop below runs it four at a time: its back edge is a TAKEN branch, which costs a lone wavefront
     // 30-60 cycles of instruction-buffer refill — 3 % of a 350-instruction substep (n_frames is 20 / 16 / 4 for the
     // built-in planar models: the remainder loop never runs for them).
-    float q_worst = 0.0f;  // (EO) the largest |n2 - 1| a renormalisation of this control step saw (pl_qupdate, QM = 1)
+    float q_worst = 0.0f;  // the largest |n2 - 1| a renormalisation of this control step saw (pl_qupdate, QM = 1)
     auto substep_qm = [&](auto qm_tag) __attribute__((always_inline)) {
       constexpr int QM = decltype(qm_tag)::value;
       // ---- (1) joints.acceleration_update ----------------------------------------------------------------
@@ -636,8 +643,8 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         }
       }
     };
-    auto substep = [&]() __attribute__((always_inline)) { substep_qm(std::integral_constant<int, EO ? 1 : 0>{}); };
-    // (EO) the control step's start, for the rare re-run with the exact renormalisation
+    auto substep = [&]() __attribute__((always_inline)) { substep_qm(std::integral_constant<int, SPECULATE ? 1 : 0>{}); };
+    // the control step's start, for the rare re-run with the exact renormalisation
     const float s_px = px, s_pz = pz, s_qw = qw, s_qy = qy, s_vx = vx, s_vz = vz, s_om = om;
     {
       phase_pad<mbd_pad_planar(LPS, MAXCOL, D0, D1, FL, RK, NFR)>();  // (code placement: tools/tune_phase.py)
@@ -649,7 +656,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         for (; fr < nfr; ++fr) substep();
       }
     }
-    if constexpr (EO) {
+    if constexpr (SPECULATE) {
       // some renormalisation of this control step left the series' range (wave-uniform test; NaN compares false, like the
       // branch it replaces): the control step again from its start, every renormalisation with its exact side selected
       if (__builtin_expect(__builtin_amdgcn_fcmpf(q_worst, 0.05f, 2 /* ogt */) != 0ull, 0)) {
