@@ -201,8 +201,13 @@ constexpr int kInStepWaitMs = 20;
 int lever(const char* name);
 bool env_flag(const char* name);
 // launch of the env's rollout instantiation; sweep = {plan_N, plan_state_stride, plan_ybar_stride} (RolloutParams), or nullptr
+// d_lp: the demo log-densities [B] accumulated inside the rollout (RolloutParams::lp) — only where rollout_fuses_logpd says so
 int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B, int H, float* d_rewss, float* d_rews,
-                   float* d_xpos, float* d_state_final, hipStream_t stream, LazyArgs* lz = nullptr, const int* sweep = nullptr);
+                   float* d_xpos, float* d_state_final, hipStream_t stream, LazyArgs* lz = nullptr, const int* sweep = nullptr,
+                   float* d_lp = nullptr);
+// whether the instantiation such a launch runs accumulates HumanoidTrack.eval_xref_logpd itself (the tracking reward compiled
+// in, one candidate per lane): the caller then passes d_lp instead of d_xpos and skips launch_logpd.  MBD_NO_FUSED_LOGPD = 1: never.
+bool rollout_fuses_logpd(const mbd_env* env, int B, int H, const int* sweep = nullptr);
 // whether a rollout launch of B candidates takes the next step's normals into spare workgroups
 bool rollout_fuses_noise(const mbd_env* env, int B, bool allow_pk2 = true);  // (allow_pk2: false for sweeps whose plans hold an odd candidate count — launch_rollout)
 int launch_logpd(const mbd_env* e, const float* d_xpos, int B, int H, float* d_out, hipStream_t s);

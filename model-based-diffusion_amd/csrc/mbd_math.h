@@ -107,6 +107,29 @@ MBD_HD q4 qrotvec_raw(q4 q, v3 th) {
 }
 // normalize(q + 0.5 (0,th) (x) q)
 MBD_HD q4 qrotvec(q4 q, v3 th) { return qnormalize(qrotvec_raw(q, th)); }
+// The same with the rare exact side of the renormalisation (|n2 - 1| > 0.05: a link turning by more than 0.45 rad in ONE
+// substep) handled by the CALLER (round 6).  For a lone wavefront per SIMD the branch costs its compare-to-branch latency,
+// ~40 cycles, even when it is never taken (tools/probes/probe_branch.hip).
+//   QM = 1  SPECULATIVE: the series unconditionally; the largest |n2 - 1| seen is kept in `worst` (one v_max).  The rollout
+//           kernels test it once per CONTROL step and re-run a control step in which it exceeded the bound, from its saved
+//           start, with QM = 2
+//   QM = 2  both sides computed, the exact one selected where it applies: the values of qnormalize, branch-free
+template <int QM>
+MBD_HD q4 qnormalize_qm(q4 q, float& worst) {
+  if constexpr (QM == 0) return qnormalize(q);
+  const float n2 = ffma(q.w, q.w, ffma(q.x, q.x, ffma(q.y, q.y, q.z * q.z)));
+  const float e = n2 - 1.0f;
+  float inv = ffma(ffma(ffma(ffma(0.2734375f, e, -0.3125f), e, 0.375f), e, -0.5f), e, 1.0f);
+  if constexpr (QM == 1) {
+    worst = fmax_(worst, fabs_(e));
+  } else {
+    const float exact = 1.0f / fsqrt(n2);
+    inv = fabs_(e) > 0.05f ? exact : inv;
+  }
+  return q4{q.w * inv, q.x * inv, q.y * inv, q.z * inv};
+}
+template <int QM>
+MBD_HD q4 qrotvec_qm(q4 q, v3 th, float& worst) { return qnormalize_qm<QM>(qrotvec_raw(q, th), worst); }
 struct axes3 {
   v3 X, Y, Z;
 };

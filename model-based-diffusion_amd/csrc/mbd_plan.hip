@@ -310,8 +310,12 @@ extern "C" int mbd_plan_sample_rollout(mbd_plan* p, int i, const uint32_t key_sa
     lz.progress_val = ++p->seq;
     p->eps_read_seq[p->eps_cur] = p->seq;
   }
+  // A5: the demo log-densities of the local shard come out of the rollout itself where its instantiation accumulates them
+  // (round 6: no [shard][H][K][3] round trip, no second launch); otherwise from the tracked positions, below
+  const bool fused_lp = c.enable_demo && rollout_fuses_logpd(e, c.shard_count, H);
   int rc = launch_rollout(e, p->d_state0, d_cand + (size_t)c.shard_begin * HNu, c.shard_count, H, p->d_rewss,
-                          d_rews_local, c.enable_demo ? p->d_xpos : nullptr, nullptr, s, p->lazy ? &lz : nullptr);
+                          d_rews_local, (c.enable_demo && !fused_lp) ? p->d_xpos : nullptr, nullptr, s, p->lazy ? &lz : nullptr,
+                          nullptr, fused_lp ? d_logpd_local : nullptr);
   if (rc != MBD_OK) return rc;
   if (p->timing) HIP_TRY(hipEventRecord(ev1, s));
   if (lz.nz_out) {
@@ -331,8 +335,7 @@ extern "C" int mbd_plan_sample_rollout(mbd_plan* p, int i, const uint32_t key_sa
     p->eps_key[nxt][1] = lz.nz_key[1];
     p->eps_valid[nxt] = true;
   }
-  // A5: demo log-densities of the local shard
-  if (c.enable_demo) {
+  if (c.enable_demo && !fused_lp) {
     rc = launch_logpd(e, p->d_xpos, c.shard_count, H, d_logpd_local, s);
     if (rc != MBD_OK) return rc;
   }

@@ -447,6 +447,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       float cposx[MAXCOL > 0 ? MAXCOL : 1], cposz[MAXCOL > 0 ? MAXCOL : 1], cdlam[MAXCOL > 0 ? MAXCOL : 1];
       bool cact[MAXCOL > 0 ? MAXCOL : 1];
       float vz_old, om_old;
+      constexpr int J1 = MAXCOL > 1 ? 1 : 0;  // (the second collider's slot, where there is one)
       // ---- (5) integrator.project_xd ------------------------------------------------------------------------
       auto project_xd = [&]() __attribute__((always_inline)) {
         vz_old = vz; om_old = om;
@@ -460,7 +461,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       // (Jacobi makes them independent, like stage (4): every contact of the link computes its impulse from the velocities
       // stage (5) left; the changes are added in collider order)
       auto resolve_velocity_pair = [&]() __attribute__((always_inline)) {
-        const f2 rcx = mk2(cposx[0], cposx[1]) - bc2(px), rcz = mk2(cposz[0], cposz[1]) - bc2(pz);
+        const f2 rcx = mk2(cposx[0], cposx[J1]) - bc2(px), rcz = mk2(cposz[0], cposz[J1]) - bc2(pz);
         const f2 vptx = fma2(bc2(om), rcz, bc2(vx)), vptz = fma2(bc2(-om), rcx, bc2(vz));
         f2 vn_prev = bc2(0.0f);
         if (FL >= 0 ? (FL & 4) != 0 : elast != 0.0f) vn_prev = fma2(bc2(-om_old), rcx, bc2(vz_old));  // (wave-uniform; with e = 0 the term is exactly 0)
@@ -470,7 +471,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         const f2 wt = fma2(rcz, rcz * bc2(iy_c), bc2(im_c));
         const f2 rest = bc2(-elast) * vn_prev;
         const f2 dvn = mk2(fmax_(rest.x, 0.0f), fmax_(rest.y, 0.0f)) - vptz;
-        const f2 jt_max = (bc2(mu) * mk2(cdlam[0], cdlam[1])) * bc2(inv_dt);
+        const f2 jt_max = (bc2(mu) * mk2(cdlam[0], cdlam[J1])) * bc2(inv_dt);
         const f2 jw = jt_max * wt;
         const f2 dvt = mk2(fmin_(jw.x, vtn.x), fmin_(jw.y, vtn.y));
         f2 q_n, q_t;
@@ -483,7 +484,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         // (EO: the three stay SELECTS — left alone the compiler sinks them under an EXEC mask, and one divergent region anywhere
         // makes it linearise the early-out's uniform if / else through flag registers: a second branch on the common path)
         if constexpr (EO) asm volatile("" : "+v"(nvx1), "+v"(nvz1), "+v"(nom1));
-        vx = cact[1] ? nvx1 : vx; vz = cact[1] ? nvz1 : vz; om = cact[1] ? nom1 : om;
+        vx = cact[J1] ? nvx1 : vx; vz = cact[J1] ? nvz1 : vz; om = cact[J1] ? nom1 : om;
       };
       {
         float cdx = 0.0f, cdz = 0.0f, cdth = 0.0f;
@@ -523,8 +524,8 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
             cdx = act1 ? ffma(im_c, Pix.y, cdx) : cdx;
             cdz = act1 ? ffma(im_c, Piz.y, cdz) : cdz;
             cdth = act1 ? cdth + dth.y : cdth;
-            cposx[0] = posx.x; cposx[1] = posx.y; cposz[0] = posz.x; cposz[1] = posz.y;
-            cdlam[0] = dlam.x; cdlam[1] = dlam.y; cact[0] = act0; cact[1] = act1;
+            cposx[0] = posx.x; cposx[J1] = posx.y; cposz[0] = posz.x; cposz[J1] = posz.y;
+            cdlam[0] = dlam.x; cdlam[J1] = dlam.y; cact[0] = act0; cact[J1] = act1;
           };
           if constexpr (EO) {
             // WAVE-UNIFORM early-out: no sphere of any lane is below the plane.  What remains of stages (4) - (6) then:

@@ -152,9 +152,10 @@ static __global__ __launch_bounds__(256) void shift_kernel(const float* __restri
 // ---- A5: demo log-densities ------------------------------------------------------------------------------
 // HumanoidTrack.eval_xref_logpd (humanoidtrack.py:98-106): xpos [B][H][K][3], xref [K][H][3].  One workgroup per
 // candidate: its K*H terms ((clip(|x - xref|, 0, .5) / .5)^2, the candidate's 3 K H floats are contiguous) are formed in
-// parallel and parked in LDS in the contract's order (k outer, t inner); thread 0 then adds them sequentially — the
-// same chain, hence the same bits, as one thread looping over K and H with a dependent round trip per term (which took
-// 60 us per diffusion step at 2048 candidates, 12 % of the step; this form: ~4 us).
+// parallel and parked in LDS; thread k then adds link k's H terms in t order (S_k), thread 0 the K sums in link order —
+// the contract's order since round 6 (rounds 1-5: one chain over all K H terms), chosen so that the rollout kernels can
+// accumulate S_k on the tracked link's lane as the control steps go by (RolloutParams::lp) and produce the same bits
+// without this launch; the standalone entry (mbd_env_xref_logpd) and the instantiations that do not accumulate use this kernel.
 constexpr int kLogpdThreads = 256, kLogpdMaxTerms = MBD_MAX_TRACK * 64;
 static __global__ __launch_bounds__(kLogpdThreads) void logpd_track_kernel(const float* __restrict__ xpos,
                                                                     const float* __restrict__ xref, int B, int H, int K,
@@ -172,10 +173,17 @@ static __global__ __launch_bounds__(kLogpdThreads) void logpd_track_kernel(const
     float s = d / 0.5f;
     term[k * H + t] = s * s;
   }
+  __shared__ float part[MBD_MAX_TRACK];
+  __syncthreads();
+  if ((int)threadIdx.x < K) {
+    float a = 0.0f;
+    for (int t = 0; t < H; ++t) a = a + term[threadIdx.x * H + t];
+    part[threadIdx.x] = a;
+  }
   __syncthreads();
   if (threadIdx.x != 0) return;
-  float acc = 0.0f;
-  for (int i = 0; i < n; ++i) acc = acc + term[i];
+  float acc = part[0];
+  for (int k = 1; k < K; ++k) acc = acc + part[k];
   lp[b] = 0.0f - acc / (float)n;
 }
 // Car2d.eval_xref_logpd (car2d.py:95-102): qs [B][H][3], xref [H][2]

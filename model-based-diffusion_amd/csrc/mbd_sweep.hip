@@ -352,11 +352,12 @@ extern "C" int mbd_sweep_run(mbd_sweep* w, const uint32_t* keys, float* mu_0ts_o
       w->events_used++;
       HIP_TRY(hipEventRecord(ev0, s));
     }
+    const bool fused_lp = c.enable_demo && rollout_fuses_logpd(e, P * N, H, sw);  // (mbd_plan.hip: the log-densities out of the rollout)
     int rc = launch_rollout(e, w->d_state0, w->d_eps[cur], P * N, H, w->d_rewss, w->d_rews,
-                            c.enable_demo ? w->d_xpos : nullptr, nullptr, s, &lz, sw);
+                            (c.enable_demo && !fused_lp) ? w->d_xpos : nullptr, nullptr, s, &lz, sw, fused_lp ? w->d_lp : nullptr);
     if (rc != MBD_OK) return rc;
     if (w->timing) HIP_TRY(hipEventRecord(ev1, s));
-    if (c.enable_demo) {
+    if (c.enable_demo && !fused_lp) {
       rc = launch_logpd(e, w->d_xpos, P * N, H, w->d_lp, s);
       if (rc != MBD_OK) return rc;
     }

@@ -436,10 +436,14 @@ ORC_API float orc_car2d_xref_logpd(const float* xs, const float* xref, int H) {
   return 0.0f - acc / (float)H;
 }
 
-/* HumanoidTrack.eval_xref_logpd (humanoidtrack.py:98-106): xpos [H][K][3], xref [K][H][3] */
+/* HumanoidTrack.eval_xref_logpd (humanoidtrack.py:98-106): xpos [H][K][3], xref [K][H][3].
+ * Order of the mean's sum (the contract; the reference's jnp.mean over the [K, H] array leaves it to XLA): link k's H terms
+ * in t order (S_k), then S_0 + S_1 + ... in link order — rows first, the way a row-major [K, H] reduction goes, and the order
+ * a rollout can accumulate as its control steps go by (round 6; rounds 1-5 ran one chain over all K H terms: 1e-7 apart). */
 ORC_API float orc_track_xref_logpd(const float* xpos, const float* xref, int H, int K) {
   float acc = 0.0f;
-  for (int k = 0; k < K; ++k)
+  for (int k = 0; k < K; ++k) {
+    float sk = 0.0f;
     for (int t = 0; t < H; ++t) {
       const float* a = &xpos[((size_t)t * K + k) * 3];
       const float* b = &xref[((size_t)k * H + t) * 3];
@@ -447,8 +451,10 @@ ORC_API float orc_track_xref_logpd(const float* xpos, const float* xref, int H, 
       float d = sqrtf(ex * ex + ey * ey + ez * ez);
       d = d < 0.0f ? 0.0f : (d > 0.5f ? 0.5f : d);
       float s = d / 0.5f;
-      acc += s * s;
+      sk += s * s;
     }
+    acc = k == 0 ? sk : acc + sk;
+  }
   return 0.0f - acc / (float)(H * K);
 }
 

@@ -1388,6 +1388,40 @@ def test_sweep_under_every_candidates_per_wavefront(gpu, name, N, H, Nd, cpw, le
         assert np.float32(r) == np.float32(r_seq)
 
 
+@pytest.mark.parametrize("N,Nd", [(96, 6), (33, 4)])
+def test_demo_log_density_accumulated_in_the_rollout_is_bit_identical(gpu, orc_omp, N, Nd, levers):
+    """Round 6: humanoidtrack's demo plans get eval_xref_logpd (humanoidtrack.py:98-106) out of the rollout kernel itself
+    (RolloutParams::lp: S_k accumulated on each tracked link's lane, one control step at a time) instead of writing x.pos
+    [N,H,5,3] for logpd_track_kernel to read back.  MBD_NO_FUSED_LOGPD = 1 forces the two-launch form of rounds 1-5: the same plan
+    bit for bit, a sweep of three plans too; and the accumulated values equal the checker's on the tracked positions the
+    rollout API returns."""
+    from mbd_hip.envs import get_env
+    from mbd_hip.planners.mbd_planner import Args, Plan, run_diffusion
+    from mbd_hip.scripts.run_mbd import run_concurrent
+    env = get_env("humanoidtrack")
+    st = env.reset(gpu.prng_key(4))
+    outs, lps = [], []
+    for off in (0, 1):
+        levers(MBD_NO_FUSED_LOGPD=off)
+        p = Plan(env, Args(env_name="humanoidtrack", Nsample=N, Hsample=50, Ndiffuse=Nd, temp_sample=0.1, enable_demo=True,
+                           disable_recommended_params=True, not_render=True))
+        p.set_state0(st)
+        outs.append(p.run(gpu.prng_key(3))[:3])
+        p.close()
+        plans = [Args(seed=s, env_name="humanoidtrack", Nsample=N, Hsample=50, Ndiffuse=Nd, temp_sample=0.1, enable_demo=True,
+                      disable_recommended_params=True, not_render=True) for s in range(3)]
+        lps.append(run_concurrent(plans, batched=True)[:2])
+    levers(MBD_NO_FUSED_LOGPD=-1)
+    assert np.array_equal(outs[0][0], outs[1][0]) and np.array_equal(outs[0][1], outs[1][1]) and outs[0][2] == outs[1][2]
+    assert all(np.array_equal(a, b) for a, b in zip(lps[0][1], lps[1][1])) and list(lps[0][0]) == list(lps[1][0])
+    # the standalone entry against the checker, in the new order of the sum
+    us = np.clip(np.random.default_rng(N).normal(size=(N, 50, env.action_size)) * 0.4, -1, 1).astype(np.float32)
+    _, xpos = env.rollout(st, us, want_xpos=True)
+    got = env.eval_xref_logpd_batch(xpos).cpu().numpy()
+    want = np.array([orc_omp.track_xref_logpd(x, env.xref) for x in xpos.cpu().numpy()], np.float32)
+    assert np.array_equal(got, want)
+
+
 # ---- two candidates per lane (mbd_pk2.h) -----------------------------------------------------------------------------
 @pytest.mark.parametrize("name,B,H,sigma", [("humanoidrun", 96, 50, 0.6), ("humanoidrun", 1, 3, 0.3),
                                             ("humanoidrun", 37, 20, 0.9), ("humanoidtrack", 64, 50, 0.4),
