@@ -391,12 +391,15 @@ extern "C" int mbd_plan_score_update(mbd_plan* p, int i, const uint32_t key_samp
       // XCD pinning (mbd_step_kernels.h pinned_tile): the T tiles on the fewest XCDs X in {1, 2, 4, 8} that give every tile
       // a CU of its own (32 per XCD) and keep an XCD's share of the candidates' rows within its 4 MB L2; the launch is
       // 8 ceil(T / X) workgroups long, those of the other XCDs leave at once.  MBD_WMEAN_XCDS = 1 / 2 / 4 / 8 forces X.
-      const int T = (HNu + kWmE - 1) / kWmE;
+      // outputs per thread: one (two measured slower at every size and no lighter: mbd_step_kernels.h).  MBD_WMEAN_V1 = 2 forces two.
+      const int V = lever("MBD_WMEAN_V1") == 2 ? 2 : 1;
+      const int T = (HNu + kWmE * V - 1) / (kWmE * V);
       int X = 1;
       while (X < 8 && ((T + X - 1) / X > 32 || (size_t)N * HNu * sizeof(float) / X > (size_t)4 << 20)) X *= 2;
       const int x_env = lever("MBD_WMEAN_XCDS");
       if (x_env == 1 || x_env == 2 || x_env == 4 || x_env == 8) X = x_env;
-      hipLaunchKernelGGL(score_wmean_kernel, dim3(8 * ((T + X - 1) / X)), dim3(kWmE * kWmG), sizeof(float) * (size_t)N,
+      auto kern = V == 2 ? score_wmean_kernel<2> : score_wmean_kernel<1>;
+      hipLaunchKernelGGL(kern, dim3(8 * ((T + X - 1) / X)), dim3(kWmE * kWmG), sizeof(float) * (size_t)N,
                          s, d_rews_all, c.enable_demo ? d_logpd_all : nullptr, N, p->env->rew_xref, c.temp_sample,
                          c.update_method == 0 ? 1 : 0, p->d_weights, d_rew_mean, d_cand, HNu, d_Ybar_i, p->alphas[i],
                          p->alphas_bar[i], p->alphas_bar[i - 1], lit, d_Ybar_im1, lazy, sigma_i, p->d_ybar_keep, T, X);

@@ -608,6 +608,17 @@ __device__ __forceinline__ int pinned_tile(int i, int T, int X) {
   const int c = i & 7, per = (T + X - 1) / X, t = c * per + (i >> 3);
   return (c < X && (i >> 3) < per && t < T) ? t : -1;
 }
+// V (round 6): outputs per thread of the single-plan launch, like the sweeps'.  Built to test the round-5 verdict's reading of
+// the launch's extra traffic at large N (1.30x its algorithmic bytes at N = 8192, 1.15x at 4096) as half-line sharing between
+// neighbouring tiles; MEASURED (profiles/r06_score_v1_ab.txt): V = 2 moves the bytes by 0 ... 3 % (36.3 -> 35.2 MB) and makes
+// the kernel 45 ... 55 % SLOWER (27 workgroups in flight instead of 54: 15.5 -> 22.4 us at N = 4096, 25.3 -> 38.8 at 8192).
+// The extra bytes are the XCD partition's boundary lines instead: a candidate's row is 3400 bytes — not a multiple of the
+// 128-byte line — so the 448 bytes of a row that one XCD's seven tiles own (N = 8192: X = 8) start anywhere in a line and
+// touch 4.5 lines on average for 3.5 lines of data, 1.29x; fourteen tiles (N = 4096: X = 4) 8 for 7, 1.14x — the measured
+// ratios.  Only a row stride padded to whole lines would remove them (the normals' flat index would then no longer be their
+// address: sampler, rollout fetch and the peek entries all change) — for a launch that is 3 % of a step.  V = 1 stays the
+// library's choice at every size; MBD_WMEAN_V1 = 2 runs this form (same chains, same order, same bits).
+template <int V>
 static __global__ __launch_bounds__(kWmE * kWmG) void score_wmean_kernel(
     const float* __restrict__ rews, const float* __restrict__ lp_demo, int N, float rew_xref, float temp, int std_guard,
     float* __restrict__ weights_out, float* __restrict__ rew_mean_out, const float* __restrict__ Y0s, int HNu,
@@ -615,7 +626,7 @@ static __global__ __launch_bounds__(kWmE * kWmG) void score_wmean_kernel(
     float* __restrict__ Ybar_im1, int lazy, float sigma, float* __restrict__ ybar_keep, int T, int X) {
   const int tile = pinned_tile(blockIdx.x, T, X);
   if (tile < 0) return;  // (wave-uniform: the whole workgroup)
-  score_wmean_body<48, true>(rews, lp_demo, N, rew_xref, temp, std_guard, weights_out, rew_mean_out, Y0s, HNu, Ybar_i, alpha_i,
+  score_wmean_body<48, true, V>(rews, lp_demo, N, rew_xref, temp, std_guard, weights_out, rew_mean_out, Y0s, HNu, Ybar_i, alpha_i,
                    alpha_bar_i, alpha_bar_im1, literal, Ybar_im1, lazy, sigma, ybar_keep, tile, tile == 0);
 }
 // SWEEPS (mbd_sweep_*): the same for P plans of one env in ONE launch — blockIdx.y is the plan, whose buffers sit at

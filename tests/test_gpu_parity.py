@@ -1282,7 +1282,8 @@ def test_phase2_kernel_variants_and_shared_device_are_bit_identical(gpu, name, N
     other.close()
     assert np.array_equal(mu, mu0) and np.array_equal(rm, rm0) and rf == rf0 and np.array_equal(w, w0)
 
-@pytest.mark.parametrize("name,N,H", [("humanoidrun", 1024, 50), ("hopper", 333, 50), ("halfcheetah", 200, 17), ("car2d", 128, 30)])
+@pytest.mark.parametrize("name,N,H", [("humanoidrun", 1024, 50), ("hopper", 333, 50), ("halfcheetah", 200, 17), ("car2d", 128, 30),
+                                      ("humanoidrun", 4096, 50), ("humanoidrun", 8192, 50), ("halfcheetah", 2500, 17)])
 def test_score_launch_layouts_are_bit_identical(gpu, name, N, H, levers):
     """Round 5: the single-plan score + weighted-mean launch is pinned to X of the 8 XCDs (MBD_WMEAN_XCDS; the library picks X
     from the tile count and the candidates' bytes) and the sweeps' batch launch gives a thread V outputs (MBD_WMEAN_V; default 2).
@@ -1307,7 +1308,12 @@ def test_score_launch_layouts_are_bit_identical(gpu, name, N, H, levers):
         mu, rm, rf = run()
         assert np.array_equal(mu, mu0) and np.array_equal(rm, rm0) and rf == rf0, x
     levers(MBD_WMEAN_XCDS=-1)
-    if name == "car2d":
+    for v in (1, 2):  # (round 6: outputs per thread of the single-plan launch; the library keeps 1 — 2 measured slower, no lighter)
+        levers(MBD_WMEAN_V1=v)
+        mu, rm, rf = run()
+        assert np.array_equal(mu, mu0) and np.array_equal(rm, rm0) and rf == rf0, v
+    levers(MBD_WMEAN_V1=-1)
+    if name == "car2d" or N > 1024:
         return
     plans = [Args(seed=s, env_name=name, Nsample=min(N, 256), Hsample=H, Ndiffuse=5, temp_sample=0.1, disable_recommended_params=True,
                   not_render=True) for s in range(8)]
