@@ -171,6 +171,11 @@ typedef struct mbd_model {
 /* ------------------------------------------------------------------------------------------------ */
 const char* mbd_last_error(void);
 int mbd_version(void);
+/* The word of specification switches (mbd_model_flags, MBD_SPEC_FLAGS) this BUILD's tuned kernels compile in: models whose
+ * switches equal it run them, any other word runs the general instantiations that read the switches per launch (same results,
+ * a third to a half of the speed).  0 in the shipped library; -DMBD_TUNED_SPEC=<word> rebuilds it (no
+ * counterpart in the reference, whose physics has ONE specification — Brax's, which no vector pins yet). */
+int mbd_tuned_spec(void);
 /* number of usable gfx950 devices (0 on a box without a GPU — every compute entry then returns
  * MBD_ERR_NO_DEVICE; there is deliberately no CPU fallback in this library). */
 int mbd_device_count(int* count);

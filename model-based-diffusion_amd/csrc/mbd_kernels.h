@@ -25,6 +25,18 @@
 #include "../../include/mbd_hip.h"
 #include "mbd_math.h"
 
+// The specification the TUNED instantiations compile in: a word of mbd_model_flags' switches, 0 in the shipped
+// library.  A model whose switches equal it runs the tuned kernels; any other word runs the general SPEC instantiations, which
+// read the switches at run time — at a third to a half of the speed (profiles/r06_spec_cost.txt).  So the day a golden vector of
+// Brax decides a switch the other way, the answer is a REBUILD with -DMBD_TUNED_SPEC=<word> (tools/build_variant.py; build()
+// keeps lib/variants/libmbd_hip_avg.so = contact_avg, the likeliest, held bit-exact to the flagged checker by the GPU suite).
+// Switches the tuned kernels can compile in: contact_avg, contact6_gauss_seidel, friction_vel_bound, restitution_min.
+#ifndef MBD_TUNED_SPEC
+#define MBD_TUNED_SPEC 0
+#endif
+static_assert((MBD_TUNED_SPEC & ~(MBD_FLAG_CONTACT_AVG | MBD_FLAG_CONTACT6_GAUSS_SEIDEL | MBD_FLAG_FRICTION_VEL_BOUND | MBD_FLAG_RESTITUTION_MIN)) == 0,
+              "MBD_TUNED_SPEC: euler_extrinsic and gyroscopic exist in the SPEC instantiations only");
+
 namespace mbd {
 
 constexpr int kMaxChildren = 4;
@@ -1019,7 +1031,8 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
   const float rp0 = Mg->reward_params[0], rp1 = Mg->reward_params[1];
   const float dt_ctrl = Mg->dt * (float)nfr;
   // SPEC: the model's specification switches, wave-uniform (0 in every other instantiation: the tests below fold away)
-  const int spec = SPEC ? (Mg->flags & MBD_SPEC_FLAGS) : 0;
+  const int spec = SPEC ? (Mg->flags & MBD_SPEC_FLAGS) : MBD_TUNED_SPEC;  // (a constant in the tuned instantiations)
+  constexpr bool SPEC_AVG = SPEC || (MBD_TUNED_SPEC & MBD_FLAG_CONTACT_AVG) != 0;  // (code that only this switch needs)
   const bool sp_avg = (spec & MBD_FLAG_CONTACT_AVG) != 0, sp_gs = (spec & MBD_FLAG_CONTACT6_GAUSS_SEIDEL) != 0;
   const bool sp_fvel = (spec & MBD_FLAG_FRICTION_VEL_BOUND) != 0, sp_rmin = (spec & MBD_FLAG_RESTITUTION_MIN) != 0;
   const bool sp_ext = (spec & MBD_FLAG_EULER_EXTRINSIC) != 0, sp_gyro = !ISO && (spec & MBD_FLAG_GYROSCOPIC) != 0;
@@ -1597,7 +1610,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           con_pos[j] = pos; con_dlam[j] = dlam; con_act[j] = active;
         }
         }
-        if constexpr (SPEC) {
+        if constexpr (SPEC_AVG && MAXCOL > 1) {
           int n_act = 0;
 #pragma unroll
           for (int j = 0; j < MAXCOL; ++j) n_act += con_act[j] ? 1 : 0;
@@ -1631,7 +1644,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
       const v3 v6 = v, w6 = w;
       auto slot6 = [&](int j) __attribute__((always_inline)) {
           v3 rc = sub(con_pos[j], p);
-          const v3 see_v = (SPEC && sp_gs) ? v : v6, see_w = (SPEC && sp_gs) ? w : w6;
+          const v3 see_v = sp_gs ? v : v6, see_w = sp_gs ? w : w6;
           v3 vpt = add(see_v, cross(see_w, rc));
           // restitution needs the pre-solve normal velocity only when elasticity != 0 (wave-uniform); with
           // e = 0 the term max(-e*vn_prev, 0) is exactly 0
@@ -1646,9 +1659,9 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           v3 icn = iinv_z0<ISO, AXI>(ic, Wc, cn), icd = iinv<ISO, AXI>(ic, Wc, cdv);
           float wn = ic.inv_mass + dot_az0(cn, icn), wt = ic.inv_mass + dot(cdv, icd);
           float rest = -elast * vn_prev;
-          float dvn = ((SPEC && sp_rmin) ? fmin_(rest, 0.0f) : fmax_(rest, 0.0f)) - vn;  // (the floor's normal is +z: an approaching contact has vn_prev < 0)
+          float dvn = (sp_rmin ? fmin_(rest, 0.0f) : fmax_(rest, 0.0f)) - vn;  // (the floor's normal is +z: an approaching contact has vn_prev < 0)
           float jt_max = (mu * con_dlam[j]) * inv_dt;
-          float dvt = fmin_((SPEC && sp_fvel) ? jt_max : jt_max * wt, vtn);
+          float dvt = fmin_(sp_fvel ? jt_max : jt_max * wt, vtn);
           const f2 q_nt = div2_sp_(mk2(dvn, dvt), mk2(wn, wt));
           float jn = q_nt.x, jt = -q_nt.y;
           v3 Pimp = mk3(dir.x * jt, dir.y * jt, jn);
@@ -1664,7 +1677,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         if (SKIP6 && j > 0 && __builtin_expect(__builtin_amdgcn_ballot_w64(con_act[j]) == 0ull, 1)) continue;
         slot6(j);
       }
-      if constexpr (SPEC) {
+      if constexpr (SPEC_AVG && MAXCOL > 1) {
         if (!sp_gs && sp_avg) {  // the average of the link's velocity changes: v6 + (v - v6) / n
           int n_act = 0;
 #pragma unroll

@@ -23,6 +23,9 @@
 
 namespace mbd {
 
+// (of the specification switches a tuned build may compile in, MBD_TUNED_SPEC, this kernel knows contact_avg; a build with any
+// other keeps its launches on the one-candidate kernels: rollout_uses_pk2, mbd_env.hip)
+
 struct b2 {
   bool x, y;
 };
@@ -479,6 +482,17 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
           cd_th = sel3(active, ncd_th, cd_th);
           con_pos[j] = pos; con_dlam[j] = dlam; con_act[j] = active;
         }
+        // (MBD_TUNED_SPEC with contact_avg, links with several colliders: the average over a candidate's active contacts —
+        // two or more; one: untouched — per half, the operations of rollout_kernel's SPEC form)
+        if constexpr ((MBD_TUNED_SPEC & MBD_FLAG_CONTACT_AVG) != 0 && MAXCOL > 1) {
+          int nx = 0, ny = 0;
+#pragma unroll
+          for (int j = 0; j < MAXCOL; ++j) { nx += con_act[j].x ? 1 : 0; ny += con_act[j].y ? 1 : 0; }
+          const f2 inv_n = mk2(1.0f / (float)(nx > 1 ? nx : 1), 1.0f / (float)(ny > 1 ? ny : 1));
+          const b2 many{nx >= 2, ny >= 2};
+          cd_p = sel3(many, scale2(cd_p, inv_n), cd_p);
+          cd_th = sel3(many, scale2(cd_th, inv_n), cd_th);
+        }
         p = add2(p, cd_p);
         r = qrotvec2(r, cd_th);
         Pp_next = shfl3x2(p, plane);  // consumed by stage (1) of the next substep
@@ -525,6 +539,17 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
         const v3x2 nw = add2(w, scale2s(cross2(rc, Pimp), ic_ib));
         v = sel3(con_act[j], nv, v);
         w = sel3(con_act[j], nw, w);
+      }
+      if constexpr ((MBD_TUNED_SPEC & MBD_FLAG_CONTACT_AVG) != 0 && MAXCOL > 1) {  // the average of the velocity changes: v6 + (v - v6) / n
+        int nx = 0, ny = 0;
+#pragma unroll
+        for (int j = 0; j < MAXCOL; ++j) { nx += con_act[j].x ? 1 : 0; ny += con_act[j].y ? 1 : 0; }
+        const f2 inv_n = mk2(1.0f / (float)(nx > 1 ? nx : 1), 1.0f / (float)(ny > 1 ? ny : 1));
+        const b2 many{nx >= 2, ny >= 2};
+        const v3x2 av_ = v3x2{fma2(v.x - v6.x, inv_n, v6.x), fma2(v.y - v6.y, inv_n, v6.y), fma2(v.z - v6.z, inv_n, v6.z)};
+        const v3x2 aw_ = v3x2{fma2(w.x - w6.x, inv_n, w6.x), fma2(w.y - w6.y, inv_n, w6.y), fma2(w.z - w6.z, inv_n, w6.z)};
+        v = sel3(many, av_, v);
+        w = sel3(many, aw_, w);
       }
     };
     if constexpr (NFR > 1) {

@@ -107,6 +107,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   static_assert(NFR % 2 == 0, "NFR: two iterations of NFR / 2");
   static_assert(!SPEC || (D0 == 0 && FL < 0), "SPEC: the general shuffle-exchange instantiation");
   static_assert(!EO || (MAXCOL == 2 && !SPEC), "EO: the packed two-collider contact stages");
+  static_assert(!EO || (MBD_TUNED_SPEC & MBD_FLAG_CONTACT6_GAUSS_SEIDEL) == 0, "EO: stage (6) as a packed pair (Jacobi)");
   constexpr bool DPP = D0 != 0;
   // the renormalisations' rare exact side is SPECULATED away (pl_qupdate QM = 1: no compare-to-branch latency in the substep;
   // a control step in which it would have been taken is re-run).  MBD_PLANAR_NO_SPECULATE: the branches of rounds 1-5 (A/B).
@@ -235,7 +236,9 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   const int rkind = RK >= 0 ? RK : M->reward_kind;
   const float rp0 = M->reward_params[0], rp1 = M->reward_params[1];
   const float dt_ctrl = M->dt * (float)nfr;
-  const int spec = SPEC ? (M->flags & MBD_SPEC_FLAGS) : 0;  // (wave-uniform; 0 elsewhere: the tests below fold away)
+  const int spec = SPEC ? (M->flags & MBD_SPEC_FLAGS) : MBD_TUNED_SPEC;  // (wave-uniform; a constant in the tuned instantiations: the tests below fold away)
+  constexpr bool SPEC_AVG = SPEC || (MBD_TUNED_SPEC & MBD_FLAG_CONTACT_AVG) != 0;
+  constexpr bool TUNED_GS = !SPEC && (MBD_TUNED_SPEC & MBD_FLAG_CONTACT6_GAUSS_SEIDEL) != 0;  // (stage (6) cannot be a packed pair then)
   const bool sp_avg = (spec & MBD_FLAG_CONTACT_AVG) != 0, sp_gs = (spec & MBD_FLAG_CONTACT6_GAUSS_SEIDEL) != 0;
   const bool sp_fvel = (spec & MBD_FLAG_FRICTION_VEL_BOUND) != 0, sp_rmin = (spec & MBD_FLAG_RESTITUTION_MIN) != 0;
 
@@ -461,6 +464,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       // (Jacobi makes them independent, like stage (4): every contact of the link computes its impulse from the velocities
       // stage (5) left; the changes are added in collider order)
       auto resolve_velocity_pair = [&]() __attribute__((always_inline)) {
+        const float vx6 = vx, vz6 = vz, om6 = om;  // (what stage (5) left — only the averaged form reads them again)
         const f2 rcx = mk2(cposx[0], cposx[J1]) - bc2(px), rcz = mk2(cposz[0], cposz[J1]) - bc2(pz);
         const f2 vptx = fma2(bc2(om), rcz, bc2(vx)), vptz = fma2(bc2(-om), rcx, bc2(vz));
         f2 vn_prev = bc2(0.0f);
@@ -470,9 +474,9 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         const f2 wn = fma2(icn, rcx, bc2(im_c));
         const f2 wt = fma2(rcz, rcz * bc2(iy_c), bc2(im_c));
         const f2 rest = bc2(-elast) * vn_prev;
-        const f2 dvn = mk2(fmax_(rest.x, 0.0f), fmax_(rest.y, 0.0f)) - vptz;
+        const f2 dvn = (sp_rmin ? mk2(fmin_(rest.x, 0.0f), fmin_(rest.y, 0.0f)) : mk2(fmax_(rest.x, 0.0f), fmax_(rest.y, 0.0f))) - vptz;
         const f2 jt_max = (bc2(mu) * mk2(cdlam[0], cdlam[J1])) * bc2(inv_dt);
-        const f2 jw = jt_max * wt;
+        const f2 jw = sp_fvel ? jt_max : jt_max * wt;
         const f2 dvt = mk2(fmin_(jw.x, vtn.x), fmin_(jw.y, vtn.y));
         f2 q_n, q_t;
         div2x2_sp_(dvn, wn, dvt, wt, q_n, q_t);
@@ -485,6 +489,14 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         // makes it linearise the early-out's uniform if / else through flag registers: a second branch on the common path)
         if constexpr (EO) asm volatile("" : "+v"(nvx1), "+v"(nvz1), "+v"(nom1));
         vx = cact[J1] ? nvx1 : vx; vz = cact[J1] ? nvz1 : vz; om = cact[J1] ? nom1 : om;
+        if constexpr (SPEC_AVG) {
+          if (sp_avg) {  // both touch: the average of the link's two velocity changes, v6 + (v - v6) / 2
+            const bool both = cact[0] && cact[J1];
+            vx = both ? ffma(vx - vx6, 0.5f, vx6) : vx;
+            vz = both ? ffma(vz - vz6, 0.5f, vz6) : vz;
+            om = both ? ffma(om - om6, 0.5f, om6) : om;
+          }
+        }
       };
       {
         float cdx = 0.0f, cdz = 0.0f, cdth = 0.0f;
@@ -524,6 +536,10 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
             cdx = act1 ? ffma(im_c, Pix.y, cdx) : cdx;
             cdz = act1 ? ffma(im_c, Piz.y, cdz) : cdz;
             cdth = act1 ? cdth + dth.y : cdth;
+            if constexpr (!SPEC && (MBD_TUNED_SPEC & MBD_FLAG_CONTACT_AVG) != 0) {  // both touch: half the summed correction
+              const bool both = act0 && act1;                                        // (SPEC: averaged below, like any MAXCOL)
+              cdx = both ? cdx * 0.5f : cdx; cdz = both ? cdz * 0.5f : cdz; cdth = both ? cdth * 0.5f : cdth;
+            }
             cposx[0] = posx.x; cposx[J1] = posx.y; cposz[0] = posz.x; cposz[J1] = posz.y;
             cdlam[0] = dlam.x; cdlam[J1] = dlam.y; cact[0] = act0; cact[J1] = act1;
           };
@@ -605,14 +621,14 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       // order (SPEC, contact6_gauss_seidel: one after the other, each from the running values)
       if constexpr (EO) {
         // (done above, on the path that had a contact)
-      } else if constexpr (MAXCOL == 2 && !SPEC) {
+      } else if constexpr (MAXCOL == 2 && !SPEC && !TUNED_GS) {
         resolve_velocity_pair();
       } else if constexpr (MAXCOL > 0) {
         const float vx6 = vx, vz6 = vz, om6 = om;  // what every contact of the link sees
 #pragma unroll
         for (int j = 0; j < MAXCOL; ++j) {
           const float rcx = cposx[j] - px, rcz = cposz[j] - pz;
-          const float svx = (SPEC && sp_gs) ? vx : vx6, svz = (SPEC && sp_gs) ? vz : vz6, som = (SPEC && sp_gs) ? om : om6;
+          const float svx = sp_gs ? vx : vx6, svz = sp_gs ? vz : vz6, som = sp_gs ? om : om6;
           const float vptx = ffma(som, rcz, svx), vptz = ffma(-som, rcx, svz);
           float vn_prev = 0.0f;
           if (FL >= 0 ? (FL & 4) != 0 : elast != 0.0f) vn_prev = ffma(-om_old, rcx, vz_old);  // (wave-uniform; with e = 0 the term is exactly 0)
@@ -622,16 +638,16 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
           const float wn = ffma(icn, rcx, im_c);
           const float wt = ffma(rcz, rcz * iy_c, im_c);
           const float rest = -elast * vn_prev;
-          const float dvn = ((SPEC && sp_rmin) ? fmin_(rest, 0.0f) : fmax_(rest, 0.0f)) - vptz;
+          const float dvn = (sp_rmin ? fmin_(rest, 0.0f) : fmax_(rest, 0.0f)) - vptz;
           const float jt_max = (mu * cdlam[j]) * inv_dt;
-          const float dvt = fmin_((SPEC && sp_fvel) ? jt_max : jt_max * wt, vtn);
+          const float dvt = fmin_(sp_fvel ? jt_max : jt_max * wt, vtn);
           const f2 q_nt = div2_sp_(mk2(dvn, dvt), mk2(wn, wt));
           const float Pix = -__builtin_copysignf(q_nt.y, vptx), Piz = q_nt.x;  // friction opposes the slip
           const float nvx = ffma(im_c, Pix, vx), nvz = ffma(im_c, Piz, vz);
           const float nom = om + pl_cross(rcx, rcz, Pix, Piz) * iy_c;
           vx = cact[j] ? nvx : vx; vz = cact[j] ? nvz : vz; om = cact[j] ? nom : om;
         }
-        if constexpr (SPEC) {
+        if constexpr (SPEC_AVG) {
           if (!sp_gs && sp_avg) {  // the average of the link's velocity changes: v6 + (v - v6) / n
             int n_act = 0;
 #pragma unroll

@@ -12,7 +12,7 @@ namespace mbd {
 // the early-out instantiations (EO: P.cpw candidates per wavefront, mbd_planar.h): (lps, family, fl, rk, nfr) of the built-in
 // models with contacts — hopper, walker2d, halfcheetah
 bool planar_has_early_out(int lps, int dpp_family, int max_col, int fl, int rk, int nfr) {
-  if (max_col != 2) return false;
+  if (max_col != 2 || (MBD_TUNED_SPEC & MBD_FLAG_CONTACT6_GAUSS_SEIDEL) != 0) return false;  // (stage (6) as a packed pair is Jacobi)
   if (lps == 4 && dpp_family == 2) return fl == 0 && rk == MBD_REW_HOPPER && nfr == 20;
   if (lps == 8 && dpp_family == 1)
     return (fl == 0 && rk == MBD_REW_HOPPER && nfr == 20) || (fl == 1 && rk == MBD_REW_HALFCHEETAH);
@@ -23,11 +23,13 @@ hipError_t launch_rollout_planar(int lps, int dpp_family, int max_col, int fl, i
                                  dim3 grid, dim3 block, size_t lds, hipStream_t stream, const RolloutParams& P) {
 #define PL(...) return launch_rollout_kernel(rollout_planar_kernel<__VA_ARGS__>, device, grid, block, lds, stream, P)
   if (spec) PL(16, 2, 0, 0, -1, -1, 0, true);  // specification switches at run time
+#if (MBD_TUNED_SPEC & 8) == 0
   if (P.cpw > 0) {  // (the launch geometry asked planar_has_early_out first)
     if (lps == 4) PL(4, 2, 1, 0, 0, MBD_REW_HOPPER, 20, false, true);
     if (rk == MBD_REW_HOPPER) PL(8, 2, 1, -3, 0, MBD_REW_HOPPER, 20, false, true);
     PL(8, 2, 1, -3, 1, MBD_REW_HALFCHEETAH, 0, false, true);
   }
+#endif
   // (... the reward kind: cartpole, hopper, walker2d, halfcheetah; and n_frames, for the values the built-in models have:
   // NFR.  Not for halfcheetah, n_frames = 16: 2 x 8 in line measured -0.2 %, 4 x 4 with a constant trip count -0.9 % — its
   // substep compiles to 399 / 402 instructions instead of 398)

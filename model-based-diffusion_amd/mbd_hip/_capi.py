@@ -35,7 +35,7 @@ class PlanConfig(C.Structure):
 
 
 EXPORTS = [
-    "mbd_last_error", "mbd_version", "mbd_device_count", "mbd_prng_key", "mbd_prng_split",
+    "mbd_last_error", "mbd_version", "mbd_tuned_spec", "mbd_device_count", "mbd_prng_key", "mbd_prng_split",
     "mbd_env_create", "mbd_env_name", "mbd_builtin_model", "mbd_env_get_model", "mbd_env_xref", "mbd_env_xref_logpd",
     "mbd_env_observe", "mbd_model_observe", "mbd_model_forward", "mbd_env_create_car2d", "mbd_env_create_model", "mbd_env_destroy", "mbd_env_info", "mbd_env_reset", "mbd_env_pipeline_init",
     "mbd_env_step", "mbd_env_rew_xref", "mbd_env_rollout", "mbd_plan_create", "mbd_plan_destroy",

@@ -1679,6 +1679,65 @@ def test_fallback_build_is_bit_identical(gpu, tmp_path):
         assert np.isfinite(res["main"][k]).all() and np.array_equal(res["main"][k], res["plain"][k]), k
 
 
+_AVG_PROBE = r"""
+import os, sys
+root, pkg, out = sys.argv[1:4]
+for p in (root, pkg, os.path.join(root, "tests")):
+    sys.path.insert(0, p)
+import numpy as np
+from conftest import load_model
+from mbd_hip import _capi
+from mbd_hip.envs.base import RigidBodyEnv
+from mbd_hip.planners.mbd_planner import Args, Plan
+res = {"lib": np.array(os.environ.get("MBD_HIP_LIB", "")), "tuned": np.array(_capi.load().mbd_tuned_spec())}
+for name, B, bits in (("hopper", 80, 4), ("halfcheetah", 72, 4), ("walker2d", 40, 4), ("ant", 44, 4), ("humanoidstandup", 36, 4),
+                      ("humanoidrun", 48, 4), ("ant", 4200, 4), ("hopper", 64, 0), ("humanoidstandup", 24, 0), ("hopper", 48, 4 | 16)):
+    env = RigidBodyEnv(name, model=load_model(name).with_spec(bits))
+    st = env.reset(_capi.prng_key(5))
+    H = 50 if B < 1000 else 6
+    us = np.clip(np.random.default_rng(B + bits).normal(size=(B, H, env.action_size)) * 0.5, -1.2, 1.2).astype(np.float32)
+    res[f"{name}_{B}_{bits}_state"] = np.asarray(st.pipeline_state, np.float32)
+    res[f"{name}_{B}_{bits}_us"] = us
+    res[f"{name}_{B}_{bits}_rewss"] = env.rollout(st, us).cpu().numpy()
+    if B < 1000:
+        p = Plan(env, Args(env_name=name, Nsample=B, Hsample=12, Ndiffuse=4, temp_sample=0.1, disable_recommended_params=True, not_render=True))
+        p.set_state0(st)
+        res[f"{name}_{B}_{bits}_mu"] = p.run(_capi.prng_key(3))[0]
+        p.close()
+np.savez(out, **res)
+"""
+
+
+def test_tuned_spec_variant_is_bit_exact_to_the_flagged_checker(gpu, orc_omp, tmp_path):
+    """Round 6: the tuned kernels compile a word of specification switches in, MBD_TUNED_SPEC — 0 in the library,
+    contact_avg (4) in lib/variants/libmbd_hip_avg.so, which build() keeps beside it.  Under the variant a model flagged 4 runs
+    the TUNED instantiations (planar packed pairs with their early-out, the humanoids', ant's, the helper-lane form, two
+    candidates per lane at 4200 ant candidates) and must equal the checker run with flag 4, bit for bit; a model flagged 0 or
+    4 | 16 runs the general SPEC instantiations there and must equal the checker too.  The library under test answers 0."""
+    import subprocess, sys
+    from conftest import ROOT, load_model
+    from oracle.planner import OracleEnv
+    pkg = os.path.join(ROOT, "model-based-diffusion_amd")
+    assert gpu.load().mbd_tuned_spec() == 0
+    avg = os.path.join(pkg, "lib", "variants", "libmbd_hip_avg.so")
+    assert os.path.exists(avg), "build() leaves the contact_avg build under lib/variants/"
+    env = dict(os.environ)
+    env["MBD_HIP_LIB"] = avg
+    out = str(tmp_path / "avg.npz")
+    r = subprocess.run([sys.executable, "-c", _AVG_PROBE, ROOT, pkg, out], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    res = np.load(out)
+    assert str(res["lib"]).endswith("libmbd_hip_avg.so") and int(res["tuned"]) == 4
+    cases = sorted({k.rsplit("_", 1)[0] for k in res.files if k.endswith("_rewss")})
+    assert len(cases) == 10
+    for c in cases:
+        name, B, bits = c.split("_")
+        m = load_model(name).with_spec(int(bits))
+        oe = OracleEnv(orc_omp, name, m.to_struct(), init_q=getattr(m, "init_q", None))
+        ref = oe.rollout(res[c + "_state"], res[c + "_us"])
+        assert np.isfinite(res[c + "_rewss"]).all() and np.array_equal(res[c + "_rewss"], ref), c
+
+
 def test_exchange_reports_a_peer_that_never_arrives(gpu, tmp_path):
     """A rank whose peer never pushes: its waits end at their time limit (~2 s of the wall clock, once — the flag is
     sticky), mbd_exchange_status turns that into MBD_ERR_STATE, and the process returns instead of hanging."""
