@@ -175,13 +175,16 @@ def reference_baseline(cfg, seconds_budget=25.0):
     except Exception as e:  # noqa: BLE001 — ImportError, or whatever a half-installed jax raises
         return None, f"{type(e).__name__}: {e}"
 
+    last = {}
+
     def run(nd):
         a = ref_planner.Args(seed=0, disable_recommended_params=True, not_render=True, env_name=cfg["env"],
                              Nsample=cfg["N"], Hsample=cfg["H"], Ndiffuse=nd, temp_sample=cfg["temp"],
                              enable_demo=cfg["demo"])
         t0 = time.time()
         with contextlib.redirect_stdout(sys.stderr):
-            ref_planner.run_diffusion(a)
+            rf = ref_planner.run_diffusion(a)
+        last["ndiffuse"], last["rew_final"] = nd, rf
         return time.time() - t0
 
     try:
@@ -195,10 +198,86 @@ def reference_baseline(cfg, seconds_budget=25.0):
             per = max((t_long - t_short) / K, 1e-9)
     except Exception as e:  # noqa: BLE001
         return None, f"reference run failed: {type(e).__name__}: {e}"
-    return {"value": 1.0 / per, "unit": "diffusion-steps/sec", "cores": os.cpu_count() or 1, "kind": "jax-reference",
-            "versions": {"jax": getattr(jax, "__version__", "?"), "brax": getattr(brax, "__version__", "?")},
-            "sample": f"the reference's run_diffusion on JAX's CPU backend, {cfg['env']} N={cfg['N']} H={cfg['H']}: "
-                      f"(Ndiffuse={2 + K}: {t_long:.1f} s) - (Ndiffuse=2: {t_short:.1f} s) over {K} steps"}, None
+    versions = {"jax": getattr(jax, "__version__", "?"), "brax": getattr(brax, "__version__", "?")}
+    rec = {"value": 1.0 / per, "unit": "diffusion-steps/sec", "cores": os.cpu_count() or 1, "kind": "jax-reference",
+           "versions": versions,
+           "sample": f"the reference's run_diffusion on JAX's CPU backend, {cfg['env']} N={cfg['N']} H={cfg['H']}: "
+                     f"(Ndiffuse={2 + K}: {t_long:.1f} s) - (Ndiffuse=2: {t_short:.1f} s) over {K} steps"}
+    # FIRST CONTACT with a real Brax, automatic (round 6): the box that can import jax + brax also dumps the reference's
+    # records for this line's env and holds the checker to them — no human in the loop
+    rec["parity_jax"] = parity_vs_jax(ref, cfg, versions, last)
+    return rec, None
+
+
+def parity_vs_jax(ref, cfg, versions, last_run):
+    """The `parity_jax` object of the line: what tools/dump_golden.py records of the REAL reference (jax + brax importable,
+    $MBD_REFERENCE_PATH) for this line's env — three reverse_once steps at N = min(N, 64), one physics substep stage by stage
+    from the reset pose and from a settled pose, the bounce — against this repo's checker (tools/compare_golden.py):
+      first_mismatch_stage   the first stage of Brax's substep the DEFAULT specification misses by more than 1e-5 (null: none),
+      fitted_flags / fitted  the word of DESIGN.md §9's switches that fits best (--search) and its names: a word other than this
+                             build's mbd_tuned_spec() is answered by the variant library of that word (libmbd_hip_avg.so = 4),
+      max_rel                teacher-forced: the checker's rewards on the reference's candidates of those steps vs Brax's
+                             (the north star's 1e-5), per quantity in max_rel_rewards / max_rel_ybar,
+      rew_final_ref          what the reference's last timed run_diffusion returned (seed 0, its Ndiffuse beside it; main() adds
+                             this library's rew_final of the same arguments).
+    Outside the timed region; the GPU side equals the checker bit for bit (`parity`), so checker-vs-Brax is the open half.
+    Every failure is reported inside the object — it never costs the line its value."""
+    import tempfile
+    out = {"versions": versions, "env": cfg["env"], "tolerance": 1e-5}
+    try:
+        out["rew_final_ref"], out["rew_final_ndiffuse"] = float(last_run.get("rew_final")), int(last_run.get("ndiffuse"))
+    except Exception:  # noqa: BLE001
+        pass
+    try:
+        import numpy as np
+        tools = os.path.join(ROOT, "tools")
+        if tools not in sys.path:
+            sys.path.insert(0, tools)
+        import compare_golden
+        import dump_golden
+        td = tempfile.mkdtemp(prefix="mbd_parity_jax_")
+        with contextlib.redirect_stdout(sys.stderr):
+            path = dump_golden.dump(ref, cfg["env"], min(int(cfg["N"]), 64), int(cfg["H"]), 3, out_dir=td)
+        out["golden"] = os.path.basename(path)
+        g = np.load(path)
+        out["records"] = {"reverse_once_steps": len([k for k in g.files if k.startswith("rewss_")]),
+                          "substep_stages": bool("stage_1_acceleration_x_pos" in g.files), "settled_substep": bool("contact_substep_in_x_pos" in g.files),
+                          "bounce": bool("bounce_vz" in g.files)}
+        if "substep_in_x_pos" in g.files:
+            with contextlib.redirect_stdout(sys.stderr):
+                lines, first = compare_golden.compare(path, 1e-5)
+                rows = compare_golden.search(path, 1e-5)
+            out["first_mismatch_stage"] = None if first is None else first[0]
+            if first is not None:
+                out["first_mismatch"] = {"stage": first[0], "link": int(first[1]), "quantity": first[2], "err": float(first[3])}
+            best = rows[0]
+            out["fitted_flags"], out["fitted"] = int(best[0]), list(best[1]) or ["default"]
+            out["fitted_first_mismatch_stage"] = None if best[2] is None else best[2][0]
+            out["report"] = lines[-12:]
+        # record (A), teacher-forced through the checker (the cpu_baseline leg may use it)
+        from mbd_hip.model import Model
+        from oracle import oracle as orc_mod
+        orc_mod.build()
+        orc = orc_mod.Oracle("f32")
+        with open(os.path.join(ROOT, "model-based-diffusion_amd", "assets", "compiled", f"{cfg['env']}.json")) as f:
+            m = Model.from_json(f.read()).with_spec(out.get("fitted_flags", 0) if out.get("fitted_first_mismatch_stage", 1) is None else 0)
+        ms = m.to_struct()
+        st = orc.forward(ms, np.asarray(g["q0"], np.float32), np.asarray(g["qd0"], np.float32))
+        er, ey = 0.0, 0.0
+        for k in range(out["records"]["reverse_once_steps"]):
+            rew = orc.rollout(ms, st, np.asarray(g[f"Y0s_{k}"], np.float32))
+            ref_r = np.asarray(g[f"rewss_{k}"], np.float32)
+            er = max(er, float((np.abs(rew - ref_r) / np.maximum(np.abs(ref_r), 1.0)).max()))
+            w = np.asarray(g[f"weights_{k}"], np.float64)
+            yb = np.einsum("n,nij->ij", w, np.asarray(g[f"Y0s_{k}"], np.float64))
+            ref_y = np.asarray(g[f"Ybar_{k}"], np.float64)
+            ey = max(ey, float((np.abs(yb - ref_y) / np.maximum(np.abs(ref_y), 1.0)).max()))
+        out["max_rel_rewards"], out["max_rel_ybar"], out["max_rel"] = er, ey, max(er, ey)
+        out["within_tolerance"] = bool(max(er, ey) <= 1e-5)
+        out["flags_of_the_teacher_forced_model"] = int(m.fields["flags"]) & 252
+    except Exception as e:  # noqa: BLE001
+        out["error"] = f"{type(e).__name__}: {e}"
+    return out
 
 
 def cpu_baseline(cfg, seconds_budget=15.0):
@@ -913,6 +992,17 @@ def main():
             out["cpu_baseline"], live = cpu_baseline(cfg)
             if live:
                 fsub, fsub_src = live, "oracle/count_ops.cc (this run)"
+            pj = out["cpu_baseline"].pop("parity_jax", None) if isinstance(out["cpu_baseline"], dict) else None
+            if pj is not None:
+                if "rew_final_ndiffuse" in pj and not is_sweep:  # this library's rew_final of the reference's last timed arguments
+                    try:
+                        a = Args(seed=0, env_name=ENV, Nsample=N_CFG, Hsample=H, Ndiffuse=pj["rew_final_ndiffuse"], temp_sample=TEMP,
+                                 enable_demo=DEMO, disable_recommended_params=True, not_render=True)
+                        with contextlib.redirect_stdout(sys.stderr):
+                            pj["rew_final_ours"] = float(run_diffusion(a, device=local_rank, force_single=True))
+                    except Exception as e:  # noqa: BLE001
+                        pj["rew_final_ours_error"] = f"{type(e).__name__}: {e}"
+                out["parity_jax"] = pj
             traj = out["cpu_baseline"].pop("_trajectory", None)
             if traj is not None and not is_sweep and not os.environ.get("MBD_BENCH_N"):
                 try:  # (guarded like the extras: a failure here is reported, it never costs the line its value)

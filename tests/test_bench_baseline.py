@@ -2,6 +2,7 @@
 reference) and falls back to the port.  Neither jax nor brax exists in this image, so the reference branch is
 exercised with stub modules that have the reference's call surface (mbd.planners.mbd_planner.Args / run_diffusion)."""
 import importlib
+import os
 import sys
 import textwrap
 
@@ -71,6 +72,11 @@ def test_reference_branch_with_stub_modules(bench_mod, tmp_path, monkeypatch):
         assert all(c.env_name == "humanoidrun" and c.Nsample == 1024 and c.Hsample == 50 and c.disable_recommended_params
                    and c.not_render for c in calls)
         assert calls[0].Ndiffuse == 2 and calls[-1].Ndiffuse > 2
+        # round 6: the same branch also dumps the reference's records and holds the checker to them (`parity_jax`).  The stub
+        # reference has no envs to dump: the failure is reported INSIDE the object, with what the timed run returned
+        pj = rec["parity_jax"]
+        assert pj["versions"] == {"jax": "0.0-stub", "brax": "0.0-stub"} and pj["rew_final_ref"] == 1.0
+        assert pj["rew_final_ndiffuse"] == calls[-1].Ndiffuse and "error" in pj and pj["env"] == "humanoidrun"
     finally:
         for m in ("jax", "brax", "mbd", "mbd.planners", "mbd.planners.mbd_planner"):
             sys.modules.pop(m, None)
@@ -105,3 +111,41 @@ def test_port_baseline_hands_its_trajectory_to_the_parity_leg(bench_mod):
     port, _ = bench_mod.port_baseline(bench_mod.CONFIGS["car2d"], seconds_budget=30.0)
     tr = port["_trajectory"]
     assert len(tr["mu_0ts"]) == 49 and tr["rew_final"] is not None and tr["state_init"].shape[-1] == 3
+
+
+def test_parity_jax_object_from_a_dump(bench_mod, orc, tmp_path, monkeypatch):
+    """bench.py::parity_vs_jax on a file in tools/dump_golden.py's schema (written here by THIS repo's checker under a planted
+    switch, like tests/test_golden.py's: plumbing, not a golden): the stage the default specification misses first, the word of
+    switches that fits, the teacher-forced relative error — what a box with jax + brax will put into the line."""
+    import sys
+
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import dump_golden
+    from conftest import load_model
+    from test_golden import _synthetic_stage_file
+    planted = 8   # ("Brax" = the checker with stage (6) Gauss-Seidel)
+
+    def fake_dump(ref, env_name, N, H, steps, out_dir=".", records="ABC"):
+        path = os.path.join(out_dir, f"golden_{env_name}_N{N}_H{H}.npz")
+        _synthetic_stage_file(orc, path, env_name, flags=planted, steps=20, action=0.0)
+        g = dict(np.load(path))
+        m = load_model(env_name).with_spec(planted)
+        q0, qd0 = m.init_q, np.zeros(m.qd_size(), np.float32)
+        st = orc.forward(m.to_struct(), q0, qd0)
+        Y = np.clip(np.random.default_rng(0).normal(size=(N, H, m.act_size())) * 0.5, -1, 1).astype(np.float32)
+        w = np.full(N, 1.0 / N, np.float32)
+        g.update(q0=q0, qd0=qd0, Y0s_0=Y, rewss_0=orc.rollout(m.to_struct(), st, Y), weights_0=w,
+                 Ybar_0=np.einsum("n,nij->ij", w.astype(np.float64), Y.astype(np.float64)).astype(np.float32))
+        np.savez(path, **g)
+        return path
+    monkeypatch.setattr(dump_golden, "dump", fake_dump)
+    pj = bench_mod.parity_vs_jax("/nonexistent", dict(bench_mod.CONFIGS["hopper512"], N=8, H=6), {"jax": "x", "brax": "y"},
+                                 {"rew_final": 2.5, "ndiffuse": 6})
+    assert "error" not in pj, pj
+    assert pj["rew_final_ref"] == 2.5 and pj["rew_final_ndiffuse"] == 6 and pj["golden"] == "golden_hopper_N8_H6.npz"
+    assert pj["first_mismatch_stage"] == "6_contact_velocity" or pj["first_mismatch_stage"] == "contact:6_contact_velocity"
+    assert pj["fitted_flags"] == planted and pj["fitted"] == ["contact6_gauss_seidel"] and pj["fitted_first_mismatch_stage"] is None
+    # teacher-forced under the fitted word: the checker reproduces the "reference" exactly
+    assert pj["flags_of_the_teacher_forced_model"] == planted and pj["max_rel"] < 1e-6 and pj["within_tolerance"] is True
+    assert pj["records"]["reverse_once_steps"] == 1 and pj["records"]["substep_stages"] and pj["records"]["settled_substep"]

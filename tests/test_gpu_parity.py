@@ -1681,7 +1681,7 @@ def test_fallback_build_is_bit_identical(gpu, tmp_path):
 
 _AVG_PROBE = r"""
 import os, sys
-root, pkg, out = sys.argv[1:4]
+root, pkg, out, W = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 for p in (root, pkg, os.path.join(root, "tests")):
     sys.path.insert(0, p)
 import numpy as np
@@ -1690,8 +1690,8 @@ from mbd_hip import _capi
 from mbd_hip.envs.base import RigidBodyEnv
 from mbd_hip.planners.mbd_planner import Args, Plan
 res = {"lib": np.array(os.environ.get("MBD_HIP_LIB", "")), "tuned": np.array(_capi.load().mbd_tuned_spec())}
-for name, B, bits in (("hopper", 80, 4), ("halfcheetah", 72, 4), ("walker2d", 40, 4), ("ant", 44, 4), ("humanoidstandup", 36, 4),
-                      ("humanoidrun", 48, 4), ("ant", 4200, 4), ("hopper", 64, 0), ("humanoidstandup", 24, 0), ("hopper", 48, 4 | 16)):
+for name, B, bits in (("hopper", 80, W), ("halfcheetah", 72, W), ("walker2d", 40, W), ("ant", 44, W), ("humanoidstandup", 36, W),
+                      ("humanoidrun", 48, W), ("ant", 4200, W), ("hopper", 64, 0), ("humanoidstandup", 24, 0), ("hopper", 48, W ^ 16)):
     env = RigidBodyEnv(name, model=load_model(name).with_spec(bits))
     st = env.reset(_capi.prng_key(5))
     H = 50 if B < 1000 else 6
@@ -1708,26 +1708,42 @@ np.savez(out, **res)
 """
 
 
-def test_tuned_spec_variant_is_bit_exact_to_the_flagged_checker(gpu, orc_omp, tmp_path):
+def _tuned_variants():
+    """(file name, word) of the MBD_TUNED_SPEC builds to hold to the checker: the one build() keeps (contact_avg) and whatever
+    `python tools/build_variant.py spec<word> -DMBD_TUNED_SPEC=<word>` left beside it."""
+    import glob, re
+    from conftest import ROOT
+    out = [("libmbd_hip_avg.so", 4)]
+    for f in sorted(glob.glob(os.path.join(ROOT, "model-based-diffusion_amd", "lib", "variants", "libmbd_hip_spec*.so"))):
+        m = re.search(r"libmbd_hip_spec(\d+)\.so$", f)
+        if m:
+            out.append((os.path.basename(f), int(m.group(1))))
+    return out
+
+
+@pytest.mark.parametrize("lib_name,word", _tuned_variants())
+def test_tuned_spec_variant_is_bit_exact_to_the_flagged_checker(gpu, orc_omp, tmp_path, lib_name, word):
     """Round 6: the tuned kernels compile a word of specification switches in, MBD_TUNED_SPEC — 0 in the library,
     contact_avg (4) in lib/variants/libmbd_hip_avg.so, which build() keeps beside it.  Under the variant a model flagged 4 runs
     the TUNED instantiations (planar packed pairs with their early-out, the humanoids', ant's, the helper-lane form, two
     candidates per lane at 4200 ant candidates) and must equal the checker run with flag 4, bit for bit; a model flagged 0 or
-    4 | 16 runs the general SPEC instantiations there and must equal the checker too.  The library under test answers 0."""
+    4 ^ 16 runs the general SPEC instantiations there and must equal the checker too.  The library under test answers 0.
+    (Other words — gauss_seidel, friction_vel_bound, restitution_min and their unions — build the same way; a variant named
+    libmbd_hip_spec<word>.so found beside it is held to the same bar: round 6 ran 60 = all four.)"""
     import subprocess, sys
     from conftest import ROOT, load_model
     from oracle.planner import OracleEnv
     pkg = os.path.join(ROOT, "model-based-diffusion_amd")
     assert gpu.load().mbd_tuned_spec() == 0
-    avg = os.path.join(pkg, "lib", "variants", "libmbd_hip_avg.so")
+    avg = os.path.join(pkg, "lib", "variants", lib_name)
     assert os.path.exists(avg), "build() leaves the contact_avg build under lib/variants/"
     env = dict(os.environ)
     env["MBD_HIP_LIB"] = avg
     out = str(tmp_path / "avg.npz")
-    r = subprocess.run([sys.executable, "-c", _AVG_PROBE, ROOT, pkg, out], env=env, capture_output=True, text=True, timeout=900)
+    r = subprocess.run([sys.executable, "-c", _AVG_PROBE, ROOT, pkg, out, str(word)], env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     res = np.load(out)
-    assert str(res["lib"]).endswith("libmbd_hip_avg.so") and int(res["tuned"]) == 4
+    assert str(res["lib"]).endswith(lib_name) and int(res["tuned"]) == word
     cases = sorted({k.rsplit("_", 1)[0] for k in res.files if k.endswith("_rewss")})
     assert len(cases) == 10
     for c in cases:

@@ -166,10 +166,17 @@ def dump_bounce(out):
         print(f"NOTE: the restitution record was not produced on this Brax ({type(e).__name__}: {e})")
 
 
-def main():
-    ref, env_name, N, H, steps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+def dump(ref, env_name, N, H, steps, out_dir=".", records="ABC"):
+    """Run the reference under the jax / brax that are importable HERE and write golden_<env>_N<N>_H<H>.npz into out_dir;
+    returns its path.  records: which of (A) the reverse_once steps, (B) the stage-by-stage substeps, (C) the bounce to
+    produce — (B) and (C) reach into Brax's internals and leave a note instead of a record when the installed Brax differs.
+    Importable: bench.py's reference leg calls it when `import jax, brax` succeeds (its `parity_jax` object), and
+    tests/test_dump_golden.py executes record (A) under tools/make_ref_golden.py's numpy stand-in so that this code path
+    has run before it ever meets a real Brax."""
+    import os
     sys.dont_write_bytecode = True  # importing the reference must not leave __pycache__ in its tree
-    sys.path.insert(0, ref)
+    if ref not in sys.path:
+        sys.path.insert(0, ref)
     import functools
     import brax
     import jax
@@ -189,23 +196,29 @@ def main():
     alphas_bar = jnp.cumprod(alphas)
     sigmas = jnp.sqrt(1 - alphas_bar)
     rng_exp, rng = jax.random.split(rng)
-    out = dict(jax_version=jax.__version__, brax_version=brax.__version__,
-               threefry_partitionable=bool(jax.config.jax_threefry_partitionable),
+    ps = state_init.pipeline_state
+    out = dict(jax_version=str(getattr(jax, "__version__", "?")), brax_version=str(getattr(brax, "__version__", "?")),
+               threefry_partitionable=bool(getattr(getattr(jax, "config", None), "jax_threefry_partitionable", False)),
                alphas_bar=np.asarray(alphas_bar), sigmas=np.asarray(sigmas),
-               q0=np.asarray(state_init.pipeline_state.q), qd0=np.asarray(state_init.pipeline_state.qd),
-               x0_pos=np.asarray(state_init.pipeline_state.x.pos), x0_rot=np.asarray(state_init.pipeline_state.x.rot))
-    if hasattr(env, "sys"):  # (B) one substep, stage by stage; fixed action 0.3 on every actuator
-        dump_substep_stages(env, state_init, jnp.full((Nu,), 0.3), out)
-        # (B') the same from a SETTLED state — 12 control steps under that action: the feet are on the floor, links with
-        # two colliders (hopper / walker2d / halfcheetah feet, ant legs) have both in contact
-        st = state_init
-        for _ in range(12):
-            st = step_env(st, jnp.full((Nu,), 0.3))
-        dump_substep_stages(env, st, jnp.full((Nu,), 0.3), out, prefix="contact_")
+               q0=np.asarray(ps.q), qd0=np.asarray(ps.qd), x0_pos=np.asarray(ps.x.pos), x0_rot=np.asarray(ps.x.rot))
+    if hasattr(env, "sys") and "B" in records:  # (B) one substep, stage by stage; fixed action 0.3 on every actuator
+        try:
+            dump_substep_stages(env, state_init, jnp.full((Nu,), 0.3), out)
+            # (B') the same from a SETTLED state — 12 control steps under that action: the feet are on the floor, links with
+            # two colliders (hopper / walker2d / halfcheetah feet, ant legs) have both in contact
+            st = state_init
+            for _ in range(12):
+                st = step_env(st, jnp.full((Nu,), 0.3))
+            dump_substep_stages(env, st, jnp.full((Nu,), 0.3), out, prefix="contact_")
+        except Exception as e:  # noqa: BLE001 — a Brax without these internals: the file then holds (A) only
+            print(f"NOTE: the stage-by-stage records were not produced on this Brax ({type(e).__name__}: {e})")
+    if hasattr(env, "sys") and "C" in records:
         dump_bounce(out)  # (C) the one record with elasticity != 0: settles the restitution clamp's sign convention
     Ybar = jnp.zeros([H, Nu])
     r = rng_exp
     for k, i in enumerate(range(Nd - 1, Nd - 1 - steps, -1)):
+        if "A" not in records:
+            break
         r, ks = jax.random.split(r)
         eps = jax.random.normal(ks, (N, H, Nu))
         Y0s = jnp.clip(eps * sigmas[i] + Ybar, -1.0, 1.0)
@@ -217,8 +230,14 @@ def main():
         out.update({f"key_{k}": np.asarray(ks), f"eps_{k}": np.asarray(eps), f"Y0s_{k}": np.asarray(Y0s),
                     f"rewss_{k}": np.asarray(rewss), f"weights_{k}": np.asarray(w), f"Ybar_{k}": np.asarray(Ybar),
                     f"xpos_{k}": np.asarray(qs.x.pos)})
-    np.savez_compressed(f"golden_{env_name}_N{N}_H{H}.npz", **out)
-    print("wrote", f"golden_{env_name}_N{N}_H{H}.npz")
+    path = os.path.join(out_dir, f"golden_{env_name}_N{N}_H{H}.npz")
+    np.savez_compressed(path, **out)
+    return path
+
+
+def main():
+    ref, env_name, N, H, steps = sys.argv[1], sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+    print("wrote", dump(ref, env_name, N, H, steps))
 
 
 if __name__ == "__main__":
