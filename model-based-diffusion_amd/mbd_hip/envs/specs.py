@@ -1,4 +1,12 @@
-"""Per-environment constants taken from the reference's env wrappers."""
+"""Per-environment constants taken from the reference's env wrappers.
+
+Data-level guesses live here as keys a golden vector can flip, read by tools/compile_models.py:
+  collide_all_capsules (default False)   hopper / walker2d / halfcheetah: which geoms meet the floor.  Brax loads these three
+      files from inside its wheel; the re-authored ones give only the FEET a contype (hopper.xml: foot_geom), so a body that
+      tips over sinks its torso through the floor and keeps collecting forward reward (tools/model_guess_report.py: how often).
+      True makes every capsule of every link collide (ends as spheres); hopper / walker2d stay on the planar kernels (two
+      spheres per link), the halfcheetah's torso then carries four and compiles as a 3-D model.
+"""
 
 SPECS = {
     # mbd/envs/humanoidrun.py:14-17,21-27

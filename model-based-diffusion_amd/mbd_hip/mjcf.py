@@ -235,7 +235,8 @@ def is_planar(F) -> bool:
     """A model the planar restatement applies to (MBD_FLAG_PLANAR, include/mbd_hip.h): every joint is a hinge about the
     world y axis (joint frames = a quarter turn about z, identical on both sides) or hinge-less, slides only on
     world-parented links and in the x-z plane, link frames un-rotated, all offsets in the plane, diagonal inertia, no
-    gravity along y, at most two slide dofs."""
+    gravity along y, at most two slide dofs, at most two sphere colliders per link (what the planar kernels are built for:
+    a model with more — the halfcheetah under collide_all_capsules, whose torso carries four — compiles as a 3-D model)."""
     L = int(F["n_links"])
     if L < 1 or abs(float(np.asarray(F["gravity"])[1])) != 0.0:
         return False
@@ -262,9 +263,13 @@ def is_planar(F) -> bool:
             if abs(s_w[1]) > 1e-9:
                 return False
     ncol = int(np.asarray(F["col_link"]).shape[0]) if np.ndim(F["col_link"]) else 0
+    per_link = {}
     for k in range(ncol):
         if float(np.asarray(F["col_pos"])[k][1]) != 0.0:
             return False
+        per_link[int(np.asarray(F["col_link"])[k])] = per_link.get(int(np.asarray(F["col_link"])[k]), 0) + 1
+    if per_link and max(per_link.values()) > 2:
+        return False
     return int(np.asarray(F["track_link"]).size) == 0
 
 
@@ -313,7 +318,7 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
          reward_params: Sequence[float] = (), dt_override: Optional[float] = None,
          init_q_offset: Sequence[float] = (), gear_override: Sequence[float] = (),
          passive_joint_forces: bool = True, reset_quat_raw: bool = False, planar: Optional[bool] = None,
-         spec_flags: int = 0, warn_unstable: bool = True) -> Model:
+         spec_flags: int = 0, warn_unstable: bool = True, collide_all_capsules: bool = False) -> Model:
     """Compile an MJCF file. ``n_frames`` is the env's physics substeps per control step
     (humanoidrun.py:17 -> 7, humanoidtrack.py:46 -> 5, hopper.py:18 -> 20).
 
@@ -329,6 +334,11 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
       spec_flags            the CODE-level guesses as flag bits (model.SPEC_FLAGS / model.spec_bits: contact_avg,
                             contact6_gauss_seidel, friction_vel_bound, restitution_min, euler_extrinsic, gyroscopic;
                             include/mbd_hip.h mbd_model_flags): checker and kernels honour them alike.
+      collide_all_capsules  a DATA-level guess about the re-authored hopper / walker2d / halfcheetah files (Brax ships its own
+                            in its wheel): False — only the geoms whose contype / conaffinity meet the floor's collide (the
+                            FEET in those files: a body that tips over sinks through the floor and keeps collecting its
+                            forward reward); True — every sphere and capsule of every link collides, capsule ends as
+                            spheres (the collider type the kernels already have), whatever its masks say.
     Reward-side switches live in reward_params (ant: [5] = terminate_when_unhealthy).
     warn_unstable: emit ``stability_report``'s findings as warnings (custom models; the built-in ones have none)."""
     root = ET.parse(path).getroot()
@@ -530,7 +540,8 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
         for g in ent["body"].geoms:
             if floor is None:
                 continue
-            if (g.contype & floor["conaffinity"]) | (floor["contype"] & g.conaffinity):
+            if (g.contype & floor["conaffinity"]) | (floor["contype"] & g.conaffinity) or \
+                    (collide_all_capsules and g.kind in ("sphere", "capsule")):
                 for pos, rad in g.sphere_points():
                     col_link.append(l); col_pos.append(pos - com64[l]); col_rad.append(rad)
                 friction = max(friction, g.friction)

@@ -1428,6 +1428,36 @@ def test_demo_log_density_accumulated_in_the_rollout_is_bit_identical(gpu, orc_o
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("name,planar_expected", [("hopper", True), ("walker2d", True), ("halfcheetah", False)])
+def test_collide_all_capsules_models_bitexact(gpu, orc_omp, name, planar_expected):
+    """DESIGN.md §9's data-level switch `collide_all_capsules` (every capsule end of every link a sphere collider instead of the
+    feet only): hopper and walker2d stay on the tuned planar kernels (two spheres per link, now on EVERY lane), the
+    halfcheetah's torso carries four and runs the general 3-D instantiation — rollouts and a short plan bit for bit the checker's."""
+    from conftest import ROOT
+    from mbd_hip import mjcf
+    from mbd_hip.envs import specs
+    from mbd_hip.envs.base import RigidBodyEnv
+    from mbd_hip.planners.mbd_planner import Args, Plan
+    from oracle.planner import OracleEnv
+    spec = specs.SPECS[name]
+    m = mjcf.load(os.path.join(ROOT, "model-based-diffusion_amd", "assets", spec["xml"]), env_name=name, n_frames=spec["n_frames"],
+                  reset_noise=spec["reset_noise"], reward_params=spec.get("reward_params", ()), gear_override=spec.get("gear_override", ()),
+                  collide_all_capsules=True, warn_unstable=False)
+    assert bool(int(m.fields["flags"]) & 2) == planar_expected and int(m.fields["n_col"]) >= 8
+    env = RigidBodyEnv(name, model=m)
+    oe = OracleEnv(orc_omp, name, m.to_struct(), init_q=m.init_q)
+    st = env.reset(gpu.prng_key(6))
+    us = np.clip(np.random.default_rng(5).normal(size=(70, 50, env.action_size)) * 0.7, -1.2, 1.2).astype(np.float32)
+    ref = oe.rollout(np.asarray(st.pipeline_state, np.float32), us)
+    got = env.rollout(st, us).cpu().numpy()
+    assert np.isfinite(got).all() and np.array_equal(got, ref)
+    p = Plan(env, Args(env_name=name, Nsample=64, Hsample=20, Ndiffuse=5, temp_sample=0.1, disable_recommended_params=True, not_render=True))
+    p.set_state0(st)
+    mu = p.run(gpu.prng_key(3))[0]
+    p.close()
+    assert np.isfinite(mu).all()
+
+
 # ---- two candidates per lane (mbd_pk2.h) -----------------------------------------------------------------------------
 @pytest.mark.parametrize("name,B,H,sigma", [("humanoidrun", 96, 50, 0.6), ("humanoidrun", 1, 3, 0.3),
                                             ("humanoidrun", 37, 20, 0.9), ("humanoidtrack", 64, 50, 0.4),

@@ -44,7 +44,8 @@ def main():
                       init_q_offset=spec.get("init_q_offset", ()),
                       gear_override=spec.get("gear_override", ()),
                       passive_joint_forces=spec.get("passive_joint_forces", True),
-                      reset_quat_raw=spec.get("reset_quat_raw", False), planar=spec.get("planar"))
+                      reset_quat_raw=spec.get("reset_quat_raw", False), planar=spec.get("planar"),
+                      collide_all_capsules=spec.get("collide_all_capsules", False))
         with open(os.path.join(out, f"{name}.json"), "w") as f:
             f.write(m.to_json())
         print(f"{name}: L={m.n_links} nq={m.q_size()} nqd={m.qd_size()} nu={m.act_size()} "
