@@ -484,7 +484,17 @@ def main():
                              f"rank(s) (backend {backend})")
         if backend == "nccl":
             devs = [None] * world
-            dist.all_gather_object(devs, (os.environ.get("HOSTNAME", ""), local_rank))
+            # (host name from the socket layer — $HOSTNAME is often not exported to non-interactive processes, and two nodes'
+            # ranks with the same local_rank would then collide — plus the device's own identity: two ranks that were handed
+            # the same physical GPU under different local ranks share a PCI bus id / uuid)
+            import socket
+            ident = str(local_rank)
+            try:
+                pr = torch.cuda.get_device_properties(local_rank)
+                ident = str(getattr(pr, "uuid", None) or getattr(pr, "pci_bus_id", None) or local_rank)
+            except Exception:  # noqa: BLE001
+                pass
+            dist.all_gather_object(devs, (socket.gethostname(), ident))
             if len(set(devs)) != world:
                 raise SystemExit(f"bench.py: {world} ranks share {len(set(devs))} device(s): {devs}")
 

@@ -208,6 +208,8 @@ int launch_rollout(mbd_env* env, const float* d_state0, const float* d_us, int B
 // whether the instantiation such a launch runs accumulates HumanoidTrack.eval_xref_logpd itself (the tracking reward compiled
 // in, one candidate per lane): the caller then passes d_lp instead of d_xpos and skips launch_logpd.  MBD_NO_FUSED_LOGPD = 1: never.
 bool rollout_fuses_logpd(const mbd_env* env, int B, int H, const int* sweep = nullptr);
+// whether the device is a whole 8-XCD part (the premise of the XCD-pinned launch forms)
+bool device_has_eight_xcds(const mbd_env* env);
 // whether a rollout launch of B candidates takes the next step's normals into spare workgroups
 bool rollout_fuses_noise(const mbd_env* env, int B, bool allow_pk2 = true);  // (allow_pk2: false for sweeps whose plans hold an odd candidate count — launch_rollout)
 int launch_logpd(const mbd_env* e, const float* d_xpos, int B, int H, float* d_out, hipStream_t s);

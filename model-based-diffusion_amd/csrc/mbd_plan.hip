@@ -396,6 +396,7 @@ extern "C" int mbd_plan_score_update(mbd_plan* p, int i, const uint32_t key_samp
       const int T = (HNu + kWmE * V - 1) / (kWmE * V);
       int X = 1;
       while (X < 8 && ((T + X - 1) / X > 32 || (size_t)N * HNu * sizeof(float) / X > (size_t)4 << 20)) X *= 2;
+      if (!device_has_eight_xcds(p->env)) X = 8;  // (a partition or another part: the plain launch, no empty workgroups)
       const int x_env = lever("MBD_WMEAN_XCDS");
       if (x_env == 1 || x_env == 2 || x_env == 4 || x_env == 8) X = x_env;
       auto kern = V == 2 ? score_wmean_kernel<2> : score_wmean_kernel<1>;

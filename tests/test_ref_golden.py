@@ -37,7 +37,15 @@ def score_tol(rewss, temp, sigma, demo=False, guard=True):
     std = float(rews.std())
     std = 1.0 if (guard and std < 1e-4) else max(std, 1e-12)   # (:112; path_integral.py:123 has no such guard)
     raw = 4.0 * 2.0 ** -24 * float(np.abs(rewss).max()) / (std * temp)
-    return 2e-5 + raw + (1e-3 if demo else 0.0), max(1e-5, 2e-6 + float(sigma) * raw)
+    # (round-5 advice: the data-derived bound on the weighted mean grows with a low-spread step — humanoidstandup: 3.6e-4 — so
+    # it is CAPPED at 1e-4 absolute, and the whole-run tests also hold each file to twice the error recorded for it: RECORDED_Y)
+    return 2e-5 + raw + (1e-3 if demo else 0.0), min(1e-4, max(1e-5, 2e-6 + float(sigma) * raw))
+
+
+# max |Ybar_{i-1} - file| over a file's recorded steps, as measured in round 6 (checker, f32): a regression INSIDE score_tol's bound
+# still shows when the error of a file doubles
+RECORDED_Y = {"humanoidrun": 8.4e-7, "hopper": 1.6e-6, "walker2d": 4.8e-7, "humanoidstandup": 8.4e-5, "cartpole": 3.8e-6,
+              "humanoidtrack": 6.1e-6, "humanoidtrack_demo": 4.5e-7}
 
 
 def sigma_of(i, Nd, beta0=1e-4, betaT=1e-2):
@@ -330,6 +338,7 @@ def test_whole_runs_of_the_brax_backed_wrappers_match_the_executed_reference(orc
     sched = orc.schedule(1e-4, 1e-2, Nd)
     assert list(g["i"]) == list(range(Nd - 1, 0, -1))
     nu = m.act_size()
+    worst_Y = 0.0
     for k in range(len(g["i"])):
         r2, Y, rm, det = op.reverse_once(orc, env, st0, int(g["i"][k]), g["rng_in"][k], g["Ybar_i"][k], sched, N, H, temp, 1,
                                          enable_demo=demo)
@@ -342,7 +351,9 @@ def test_whole_runs_of_the_brax_backed_wrappers_match_the_executed_reference(orc
         rtol_w, tol_Y = score_tol(g["rewss"][k], temp, sigma_of(int(g["i"][k]), Nd), demo)   # (the bound: score_tol's docstring)
         assert np.allclose(det["weights"], g["weights"][k], rtol=rtol_w, atol=1e-8), (k, rtol_w)
         assert np.abs(Y - g["Ybar_im1"][k]).max() < tol_Y, (k, tol_Y)
+        worst_Y = max(worst_Y, float(np.abs(Y - g["Ybar_im1"][k]).max()))
         assert abs(float(rm) - float(g["rew_mean"][k])) < 1e-5
+    assert worst_Y <= 2.0 * RECORDED_Y[run] + 1e-7, (run, worst_Y, RECORDED_Y[run])
     rew = env.rollout(st0, g["Ybar_im1"][-1][None])
     assert abs(float(np.mean(rew)) - float(g["rew_final"])) < 1e-5
     assert np.ptp(g["rewss"]) > 1e-3
