@@ -31,6 +31,12 @@ INSTANCES = {
     "halfcheetah_planar": "planar:8,2,1,-3,1,2",
     "walker2d_planar": "planar:8,2,1,-3,0,1,20",
     "cartpole_planar": "planar:4,0,1,0,2,5,4",
+    # the EARLY-OUT instantiations (round 6: fewer candidates per wavefront, a wave-uniform branch around the contact code): the
+    # loop's fall-through path is the substep WITHOUT a contact; `contact_path_instructions` = that path with the out-of-line
+    # contact block in place of what it skips.  Executed counts (PMC) lie between the two: profiles/r06_cpw_pmc.txt
+    "hopper_planar_eo": "planar:4,2,1,0,0,1,20,false,true",
+    "walker2d_planar_eo": "planar:8,2,1,-3,0,1,20,false,true",
+    "halfcheetah_planar_eo": "planar:8,2,1,-3,1,2,0,false,true",
     # two candidates per lane (mbd_pk2.h: rollout_pk2_kernel<MAXCOL, RK, NFR>): the counts are per candidate PAIR
     "humanoidrun_pk2": "pk2:1,0,7",
     "humanoidtrack_pk2": "pk2:1,3,5",
@@ -128,6 +134,28 @@ def count(targs):
            "s_nop_per_substep": c.get("s_nop", 0), "s_waitcnt_per_substep": c.get("s_waitcnt", 0),
            "fp32_flops_per_lane_substep": flops, "vgpr": int(vg.group(1)) if vg else None,
            "scratch_bytes": int(sc.group(1)) if sc else None}
+    # early-out instantiations: forward branches out of the loop into blocks placed behind it that jump back in
+    is_instr = lambda x: x.startswith("\t") and x.strip() and not x.strip().startswith((".", ";"))
+    cold = []
+    for k in range(bt[0], bt[1] + 1):
+        m = re.search(r"s_cbranch\w*\s+(\.LBB\d+_\d+)", body[k])
+        if not m or m.group(1) not in lab or lab[m.group(1)] <= bt[1]:
+            continue
+        t0 = lab[m.group(1)]
+        t1 = next((j for j in range(t0, len(body)) if re.search(r"s_branch\s+(\.LBB\d+_\d+)", body[j])), None)
+        if t1 is None:
+            continue
+        back = re.search(r"s_branch\s+(\.LBB\d+_\d+)", body[t1]).group(1)
+        if back not in lab or not (bt[0] <= lab[back] <= bt[1]) or lab[back] <= k:
+            continue
+        n_cold = sum(1 for x in body[t0:t1 + 1] if is_instr(x))
+        n_skip = sum(1 for x in body[k + 1:lab[back]] if is_instr(x))
+        if n_cold >= 40:  # (the contact blocks; the renormalisation's exact side and the like are a handful of instructions)
+            cold.append((n_cold, n_skip))
+    if cold:
+        res["contact_block_instructions"] = sum(c[0] for c in cold) / len(cold)
+        res["contact_path_instructions_per_substep"] = len(best) + sum(c[0] - c[1] for c in cold) / len(cold)
+        res["no_contact_path_instructions_per_substep"] = len(best)
     if os.environ.get("MBD_COUNT_DUMP"):  # the substep loop's ISA, for reading
         with open(os.environ["MBD_COUNT_DUMP"], "w") as f:
             f.write("\n".join(loop_text))
