@@ -59,8 +59,9 @@ CONFIGS = {
     # name: env, N, H, Ndiffuse, temp, demo, lanes per candidate (rollout kernel), kernel label
     "metric": dict(env="humanoidrun", N=1024, H=50, Nd=100, temp=0.1, demo=False, lps=16,
                    kernel="rollout_kernel<16,iso,noslide,3,1,dpp(1,-4,-6)>"),
-    "hopper512": dict(env="hopper", N=512, H=50, Nd=100, temp=0.1, demo=False, lps=4, static="hopper_planar",
-                      kernel="rollout_planar_kernel<4,2 colliders,dpp(1)>"),
+    # (round 6: ONE candidate per wavefront — 512 wavefronts — and a wave-uniform early-out around the contact code)
+    "hopper512": dict(env="hopper", N=512, H=50, Nd=100, temp=0.1, demo=False, lps=4, cpw=1, static="hopper_planar_eo",
+                      kernel="rollout_planar_kernel<4,2 colliders,dpp(1),early-out> (one candidate per wavefront)"),
     "halfcheetah1024": dict(env="halfcheetah", N=1024, H=50, Nd=100, temp=0.4, demo=False, lps=8,
                             static="halfcheetah_planar", kernel="rollout_planar_kernel<8,2 colliders,dpp(1,-3)>"),
     "humanoidrun4096": dict(env="humanoidrun", N=4096, H=50, Nd=100, temp=0.1, demo=False, lps=16,
@@ -138,6 +139,21 @@ def valu_view(cfg, n_local, kern_ms, n_frames, fsub, fsub_src):
                          "frac": fl / (kern_ms * 1e-3) / 1e12 / VALU_PEAK_TF,
                          "valu_instr_per_wave_substep": ent["valu_per_substep"],
                          "instr_per_wave_substep": ent["instructions_per_substep"], "source": src}
+        if "contact_path_instructions_per_substep" in ent:
+            # an early-out instantiation: the static count above is the substep WITHOUT a contact (the loop's fall-through
+            # path); one with a contact runs the out-of-line block instead.  What was EXECUTED comes from the PMC pass of the
+            # same config (SQ_INSTS_VALU / rollout wavefronts / substeps; the launch's noise workgroups add < 0.5 %)
+            eo = {"no_contact_path_instr_per_substep": ent["no_contact_path_instructions_per_substep"],
+                  "contact_path_instr_per_substep": ent["contact_path_instructions_per_substep"]}
+            pm, pm_src = committed("pmc.json")
+            for k, v in ((pm or {}).get(cfg.get("name", ""), {}) or {}).items():
+                if isinstance(v, dict) and "rollout_" in k and "SQ_INSTS_VALU" in v:
+                    ex = v["SQ_INSTS_VALU"]["avg_per_launch"] / waves / substeps
+                    eo["executed_valu_per_wave_substep"] = ex
+                    lo, hi = ent["valu_per_substep"], ent["valu_per_substep"] + (eo["contact_path_instr_per_substep"] - eo["no_contact_path_instr_per_substep"])
+                    eo["substeps_without_contact_frac"] = max(0.0, min(1.0, (hi - ex) / max(hi - lo, 1e-9)))
+                    eo["source"] = pm_src
+            out["issued"]["early_out"] = eo
     # the latency floor, measured (tools/critical_path.py: the op counter tracks the depth of every value's chain): the
     # longest chain of DEPENDENT operations of one substep of one candidate.  x 4 clocks per dependent issue x the
     # launch's substeps = the time of this rollout on a machine with unlimited lanes per candidate; the kernel issues
@@ -441,7 +457,7 @@ def main():
                     help="N > 1: the step's exchange — torch (all_gather_into_tensor: RCCL over xGMI), p2p (the in-library "
                          "windows, mbd_exchange_*), both (torch is `value`, p2p is measured after it and reported beside)")
     args = ap.parse_args()
-    cfg = CONFIGS[args.config]
+    cfg = dict(CONFIGS[args.config], name=args.config)
     ENV, N_CFG, H, ND, TEMP, DEMO = cfg["env"], cfg["N"], cfg["H"], cfg["Nd"], cfg["temp"], cfg["demo"]
     if os.environ.get("MBD_BENCH_N"):  # experiments only
         N_CFG = int(os.environ["MBD_BENCH_N"])
