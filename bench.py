@@ -937,7 +937,7 @@ def main():
                                    f"temp={TEMP}{' enable_demo' if DEMO else ''} seed=0 disable_recommended_params",
                        "name": args.config, "N_total": N_total, "N_per_gpu": N_local, "H": H, "Nu": Nu,
                        "n_frames": n_frames,
-                       "collective": (("all_gather(rews) per step through " +
+                       "collective": (("all-gather of N/G rewards per step (variant B; == all-reduce of the zero-padded vector) through " +
                                        ("torch.distributed (RCCL over xGMI)" if args.collective != "p2p" else
                                         "the in-library windows (mbd_exchange_*)") +
                                        " (variant B: every rank re-derives the softmax and the weighted mean over all N "
