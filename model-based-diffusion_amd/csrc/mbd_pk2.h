@@ -82,6 +82,25 @@ __device__ __forceinline__ q4x2 qrotvec_raw2(q4x2 q, v3x2 th) {
   return o;
 }
 __device__ __forceinline__ q4x2 qrotvec2(q4x2 q, v3x2 th) { return qnormalize2(qrotvec_raw2(q, th)); }
+// the pair form of qnormalize_qm (mbd_math.h): QM = 1 the series unconditionally, the largest |n2 - 1| of either half kept in
+// `worst`; QM = 2 both sides computed, the exact one selected per half
+template <int QM>
+__device__ __forceinline__ q4x2 qnormalize2_qm(q4x2 q, float& worst) {
+  if constexpr (QM == 0) return qnormalize2(q);
+  f2 n2 = fma2(q.w, q.w, fma2(q.x, q.x, fma2(q.y, q.y, q.z * q.z)));
+  f2 e = n2 - splat(1.0f);
+  f2 inv = fma2(fma2(fma2(fma2(splat(0.2734375f), e, splat(-0.3125f)), e, splat(0.375f)), e, splat(-0.5f)), e, splat(1.0f));
+  const float ax = fabs_(e.x), ay = fabs_(e.y);
+  if constexpr (QM == 1) {
+    worst = fmax_(worst, fmax_(ax, ay));
+  } else {
+    const float x0 = 1.0f / fsqrt(n2.x), x1 = 1.0f / fsqrt(n2.y);
+    inv = mk2(ax > 0.05f ? x0 : inv.x, ay > 0.05f ? x1 : inv.y);
+  }
+  return q4x2{q.w * inv, q.x * inv, q.y * inv, q.z * inv};
+}
+template <int QM>
+__device__ __forceinline__ q4x2 qrotvec2_qm(q4x2 q, v3x2 th, float& worst) { return qnormalize2_qm<QM>(qrotvec_raw2(q, th), worst); }
 // angle_unit_cpos on a pair
 __device__ __forceinline__ f2 angle_unit_cpos2(f2 s, f2 c) {
   f2 as = fabs2(s);
@@ -365,7 +384,18 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
       v0 = sub2(v, cross2(w, rc0));
     }
 
-    auto substep = [&]() __attribute__((always_inline)) {
+    // (the renormalisations' rare exact side speculated like the planar kernels': -DMBD_PK2_SPECULATE; measured in round 6 —
+    // see below at the substep loop)
+#ifdef MBD_PK2_SPECULATE
+    constexpr int QM_FAST = NFR > 1 ? 1 : 0;
+#else
+    constexpr int QM_FAST = 0;
+#endif
+    float q_worst = 0.0f;
+    const v3x2 s_p = p, s_v = v, s_w = w;
+    const q4x2 s_r = r;
+    auto substep_qm = [&](auto qm_tag) __attribute__((always_inline)) {
+      constexpr int QM = decltype(qm_tag)::value;
       // ---- (1) joints.acceleration_update ----------------------------------------------------------
       v3x2 Pv = shfl3x2(v, plane), Pw = shfl3x2(w, plane);
       shfl_issue();
@@ -409,7 +439,7 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
       const v3x2 p_prev = p;
       const q4x2 r_prev = r;
       p = v3x2{fma2(v.x, splat(dt), p.x), fma2(v.y, splat(dt), p.y), fma2(v.z, splat(dt), p.z)};
-      r = qrotvec2(r, scale2s(w, dt));
+      r = qrotvec2_qm<QM>(r, scale2s(w, dt), q_worst);
       // ---- (3) joints.position_update (Jacobi) ------------------------------------------------------
       dpp_fetch_p<FAM>(p, r, pm, Pp, Pr);
       {
@@ -494,7 +524,7 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
           cd_th = sel3(many, scale2(cd_th, inv_n), cd_th);
         }
         p = add2(p, cd_p);
-        r = qrotvec2(r, cd_th);
+        r = qrotvec2_qm<QM>(r, cd_th, q_worst);
         Pp_next = shfl3x2(p, plane);  // consumed by stage (1) of the next substep
         Pr_next = shfl4x2(r, plane);
         shfl_issue();
@@ -552,6 +582,7 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
         w = sel3(many, aw_, w);
       }
     };
+    auto substep = [&]() __attribute__((always_inline)) { substep_qm(std::integral_constant<int, QM_FAST>{}); };
     if constexpr (NFR > 1) {
       for (int it = 0; it < 2; ++it) repeat_n<NFR / 2>(substep);
       if constexpr (NFR % 2 != 0) substep();
@@ -559,6 +590,14 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
       int fr = 0;
       for (; fr + 1 < nfr; fr += 2) { substep(); substep(); }
       if (fr < nfr) substep();
+    }
+    if constexpr (QM_FAST == 1) {
+      if (__builtin_expect(__builtin_amdgcn_fcmpf(q_worst, 0.05f, 2 /* ogt */) != 0ull, 0)) {
+        p = s_p; r = s_r; v = s_v; w = s_w;
+        Pp_next = shfl3x2(p, plane);
+        Pr_next = shfl4x2(r, plane);
+        for (int fr = 0; fr < nfr; ++fr) substep_qm(std::integral_constant<int, 2>{});
+      }
     }
 
     // ---- reward and tracked positions ------------------------------------------------------------------
