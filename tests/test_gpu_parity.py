@@ -1458,6 +1458,37 @@ def test_collide_all_capsules_models_bitexact(gpu, orc_omp, name, planar_expecte
     assert np.isfinite(mu).all()
 
 
+@pytest.mark.parametrize("name", ["hopper", "walker2d", "halfcheetah", "cartpole"])
+def test_speculated_renormalisation_reruns_the_control_step_exactly(gpu, orc, name, levers):
+    """Round 6: the planar kernels no longer branch on the renormalisation's rare exact side (|n2 - 1| > 0.05: a link turning by
+    more than 0.45 rad in ONE substep) — they use the series unconditionally, keep the largest |n2 - 1| of the control step and
+    re-run a control step in which it exceeded the bound, from its saved start, with the exact side selected (pl_qupdate QM = 1 /
+    2).  Here a hinge starts at 400 rad/s (0.8 ... 2 rad per substep): the first control steps take the re-run, later ones do
+    not — rewards bit for bit the checker's (which branches per renormalisation), filled wavefronts and every early-out form."""
+    from conftest import load_model
+    from mbd_hip.envs import get_env
+    from mbd_hip.envs.base import State
+    env = get_env(name)
+    m = load_model(name)
+    ms = m.to_struct()
+    q = m.init_q.copy()
+    qd = np.zeros(m.qd_size(), np.float32)
+    qd[-1] = 400.0
+    ps = env.pipeline_init(q, qd)
+    st0 = orc.forward(ms, q, qd)
+    assert np.array_equal(np.asarray(ps, np.float32).reshape(st0.shape), st0)
+    st1 = orc.substep(ms, st0, np.zeros(m.act_size(), np.float32))
+    assert np.abs(st1[:, 10:13]).max() * float(m.fields["dt"]) > 0.45   # (the exact side is taken in the very first substep)
+    us = np.clip(np.random.default_rng(7).normal(size=(37, 12, env.action_size)) * 0.5, -1, 1).astype(np.float32)
+    ref = orc.rollout(ms, st0, us)
+    assert np.isfinite(ref).all()
+    for cpw in (-1, 0, 1, 2):
+        levers(MBD_CPW=cpw)
+        got = env.rollout(State(ps, None, 0.0, 0.0, {}), us).cpu().numpy()
+        assert np.array_equal(got, ref), (name, cpw, np.abs(got - ref).max())
+    levers(MBD_CPW=-1)
+
+
 # ---- two candidates per lane (mbd_pk2.h) -----------------------------------------------------------------------------
 @pytest.mark.parametrize("name,B,H,sigma", [("humanoidrun", 96, 50, 0.6), ("humanoidrun", 1, 3, 0.3),
                                             ("humanoidrun", 37, 20, 0.9), ("humanoidtrack", 64, 50, 0.4),
