@@ -282,7 +282,10 @@ def stability_report(model) -> List[str]:
         which is why the reference's XMLs pair constraint_ang_damping = 30 with spring_inertia_scale = 1 (unit tensors);
       * the joint stage SUMS the corrections of all joints of a link: with its share w_link / (w_link + w_other) of each,
         joint_scale_pos * (sum of shares) must stay below 4/3 — beyond it the pose-difference velocity feeds the overshoot
-        back and the links fly apart even in free fall."""
+        back and the links fly apart even in free fall;
+      * a joint with two or three hinge dofs reads its angles as Euler angles (x, y', z''): at a middle angle of +-90 degrees
+        they are undefined (1 / cos) and the step returns non-finite values — the middle dof needs a range inside (-90, 90)
+        (the reference's humanoids: abdomen_y -75..30, hip_z -60..35, shoulder2 -85..60; round-6 fuzz, seed 2123)."""
     F, L = model.fields, model.n_links
     dt = float(F["dt"])
     lam = [float(np.linalg.eigvalsh(np.array([[i[0], i[3], i[4]], [i[3], i[1], i[5]], [i[4], i[5], i[2]]], np.float64)).max())
@@ -305,6 +308,11 @@ def stability_report(model) -> List[str]:
         load[l] += w[l] / (w[l] + wp)
         if p >= 0:
             load[p] += wp / (w[l] + wp)
+        if int(F["n_rot"][l]) >= 2:
+            lo, hi = float(np.asarray(F["rot_lo"][l])[1]), float(np.asarray(F["rot_hi"][l])[1])
+            if lo <= -0.5 * math.pi + 0.01 or hi >= 0.5 * math.pi - 0.01:
+                out.append(f"link {model.link_names[l]!r}: the middle hinge of its {int(F['n_rot'][l])}-dof joint may reach +-90 degrees "
+                           f"(range {math.degrees(max(lo, -1e3)):.0f} .. {math.degrees(min(hi, 1e3)):.0f}): its Euler angles are undefined there; limit it inside (-90, 90)")
     jsp = float(F["joint_scale_pos"])
     if L and jsp * float(load.max()) >= 4.0 / 3.0:
         k = int(load.argmax())

@@ -111,3 +111,21 @@ def test_committed_models_match_a_fresh_compile_of_the_reference_assets():
                           drop_link_suffix=sp.get("drop_suffix"), track_names=sp.get("track", ()),
                           reset_noise=sp["reset_noise"])
         assert bytes(fresh.to_struct()) == bytes(load_model(name).to_struct()), name
+
+
+def test_stability_report_names_a_multi_dof_joint_that_can_reach_its_euler_pole():
+    """Round-6 fuzz (seed 2123): a two-dof joint whose MIDDLE hinge is unlimited turned to -90 degrees and the step returned NaN —
+    in checker and kernel alike: the joint's Euler angles are undefined there.  mjcf.stability_report says so for such a model
+    (and stays empty for one whose middle hinge is limited inside (-90, 90), like every multi-dof joint of the reference's humanoids)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from mbd_hip import mjcf
+    from test_oracle_physics import _compile
+    xml = """<mujoco><compiler angle="degree" inertiafromgeom="true"/><option timestep="0.003"/>
+<custom><numeric name="joint_scale_pos" data="0.5"/><numeric name="joint_scale_ang" data="0.2"/></custom>
+<worldbody><body name="base" pos="0 0 1"><joint type="free"/><geom type="sphere" size="0.2"/>
+ <body name="arm" pos="0.3 0 0"><joint type="hinge" axis="0 1 0" name="a" range="-60 60"/><joint type="hinge" axis="1 0 0" name="b"{rng}/>
+  <geom type="capsule" fromto="0 0 0 0 0 -0.3" size="0.04"/></body></body></worldbody></mujoco>"""
+    free = mjcf.stability_report(_compile(xml.format(rng=""), warn_unstable=False))
+    assert len(free) == 1 and "middle hinge" in free[0] and "'arm'" in free[0]
+    assert mjcf.stability_report(_compile(xml.format(rng=' range="-70 70"'), warn_unstable=False)) == []
