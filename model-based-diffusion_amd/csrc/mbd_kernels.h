@@ -946,9 +946,16 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
   // a workgroup is 1 or 4 INDEPENDENT wavefronts (nothing shared, no barrier): four-wave workgroups are how a launch
   // of >= 1024 wavefronts gets one wavefront on every SIMD of a CU (dispatch)
   const int wave_id = rblock * (blockDim.x >> 6) + (threadIdx.x >> 6);
+#ifdef MBD_PROBE_3D_CPW1
+  // (TIMING PROBE, variant builds only — docs/experiments.md §15: ONE candidate per wavefront, the other groups repeat it)
+  const int b_raw = wave_id;
+  const bool b_ok = b_raw < P.B && lane / LPS == 0;
+  const int b = b_raw < P.B ? b_raw : P.B - 1;
+#else
   const int b_raw = wave_id * SPW + lane / LPS;
   const bool b_ok = b_raw < P.B;
   const int b = b_ok ? b_raw : P.B - 1;
+#endif
   const int H = P.H, Nu = Mg->n_act, nfr = NFR > 0 ? NFR : Mg->n_frames, K = Mg->n_track;
 
   const int nr = R.nr;
@@ -1486,6 +1493,17 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
       {
         const WInert<ISO> Wc = world_inertia<ISO, DIAG, AXI>(ic, r);  // (r not yet renormalised, like the contact points)
         v3 cd_p = mk3(0, 0, 0), cd_th = mk3(0, 0, 0);
+#ifdef MBD_PROBE_NO_CONTACT
+        // (TIMING PROBE, variant builds only: the substep of a candidate that never touches — WRONG physics, the upper bound of
+        // what a contact early-out could save)
+        constexpr bool kContactCode = false;
+#else
+        constexpr bool kContactCode = true;
+#endif
+        if constexpr (!kContactCode) {
+#pragma unroll
+          for (int j = 0; j < MAXCOL; ++j) { con_pos[j] = mk3(0, 0, 0); con_dlam[j] = 0.0f; con_act[j] = false; }
+        } else
         if constexpr (MAXCOL == 2 || HELP) {
           // both colliders of the link as one packed pair (the solve is Jacobi: each sees the pose of the stage's
           // start); their corrections are then added in collider order, exactly like the loop below
@@ -1670,6 +1688,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
           v = sel3(con_act[j], nv, v);
           w = sel3(con_act[j], nw, w);
       };
+#ifndef MBD_PROBE_NO_CONTACT
 #pragma unroll
       for (int j = 0; j < MAXCOL; ++j) {
         // (one test PER slot: with one test for all of them humanoidstandup's default plan ran 1161 instead of 1284 steps/s —
@@ -1677,6 +1696,7 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
         if (SKIP6 && j > 0 && __builtin_expect(__builtin_amdgcn_ballot_w64(con_act[j]) == 0ull, 1)) continue;
         slot6(j);
       }
+#endif
       if constexpr (SPEC_AVG && MAXCOL > 1) {
         if (!sp_gs && sp_avg) {  // the average of the link's velocity changes: v6 + (v - v6) / n
           int n_act = 0;
