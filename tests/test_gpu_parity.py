@@ -775,7 +775,7 @@ def test_bench_multirank_code_path_on_rccl_with_one_rank(gpu):
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 1 and d["config"]["collective"].startswith("all_gather") and d["value"] > 300.0
+    assert d["n_gpus"] == 1 and d["config"]["collective"].startswith("all-gather of N/G rewards") and d["value"] > 300.0
 
 
 def test_bench_two_ranks_line_is_complete(gpu):
