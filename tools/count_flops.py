@@ -28,7 +28,7 @@ INSTANCES = {
     # the planar restatement (mbd_planar.h: rollout_planar_kernel<LPS, MAXCOL, D0, D1>) the planar models actually run
     # (the last argument: n_frames as a compile-time constant — the loop runs twice over n_frames / 2 substeps in line)
     "hopper_planar": "planar:4,2,1,0,0,1,20",
-    "halfcheetah_planar": "planar:8,2,1,-3,1,2",
+    "halfcheetah_planar": "planar:8,2,1,-3,1,2,16",
     "walker2d_planar": "planar:8,2,1,-3,0,1,20",
     "cartpole_planar": "planar:4,0,1,0,2,5,4",
     # the EARLY-OUT instantiations (round 6: fewer candidates per wavefront, a wave-uniform branch around the contact code): the

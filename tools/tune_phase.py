@@ -29,7 +29,7 @@ TARGETS = [
     ("3d", "16,true,false,3,1,1,-4,-6,0,false,true", (1, -1)),                    # humanoid-shaped, other rewards
     ("planar", "4,2,1,0,0,1,20", (4, 2, 1, 0, 0, 1, 20)),      # hopper
     ("planar", "8,2,1,-3,0,1,20", (8, 2, 1, -3, 0, 1, 20)),    # walker2d
-    ("planar", "8,2,1,-3,1,2", (8, 2, 1, -3, 1, 2, 0)),        # halfcheetah
+    ("planar", "8,2,1,-3,1,2,16", (8, 2, 1, -3, 1, 2, 16)),    # halfcheetah
     ("planar", "4,0,1,0,2,5,4", (4, 0, 1, 0, 2, 5, 4)),        # cartpole
 ]
 
