@@ -79,7 +79,9 @@ __device__ __forceinline__ void pl_qupdate(float& w, float& y, float dth, float&
 }
 
 // LPS lanes per candidate; D0, D1: DPP layout (lane(parent) = lane(s-th child) + Ds; D0 = 0: ds_bpermute exchange,
-// up to kMaxChildren children); MAXCOL sphere colliders per link (0: the contact stages are compiled out)
+// up to kMaxChildren children); MAXCOL sphere colliders per link (0: the contact stages are compiled out; 2: the stages as one
+// packed pair; 4 — round 6, models whose links carry three or four spheres: the halfcheetah under collide_all_capsules, its
+// torso and head capsules on one link — as two packed pairs; SPEC and a tuned Gauss-Seidel stage (6): collider by collider)
 // FL: the model's wave-uniform switches as COMPILE-TIME constants — bit 0: some hinge has a joint spring (any_stiff),
 // bit 1: some slide dof has a finite range (slide_limits), bit 2: elasticity != 0 — or -1: read them at run time.  As
 // run-time flags each is a taken forward branch per substep for the models that lack the feature (every built-in one
@@ -107,6 +109,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
   static_assert(NFR % 2 == 0, "NFR: two iterations of NFR / 2");
   static_assert(!SPEC || (D0 == 0 && FL < 0), "SPEC: the general shuffle-exchange instantiation");
   static_assert(!EO || (MAXCOL == 2 && !SPEC), "EO: the packed two-collider contact stages");
+  static_assert(MAXCOL == 0 || MAXCOL == 2 || MAXCOL == 4, "MAXCOL: colliders per link come in packed pairs");
   static_assert(!EO || (MBD_TUNED_SPEC & MBD_FLAG_CONTACT6_GAUSS_SEIDEL) == 0, "EO: stage (6) as a packed pair (Jacobi)");
   constexpr bool DPP = D0 != 0;
   // the renormalisations' rare exact side is SPECULATED away (pl_qupdate QM = 1: no compare-to-branch latency in the substep;
@@ -463,10 +466,12 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       // ---- (6) collisions.resolve_velocity (Jacobi per link), both colliders of the link as one packed pair ----
       // (Jacobi makes them independent, like stage (4): every contact of the link computes its impulse from the velocities
       // stage (5) left; the changes are added in collider order)
-      auto resolve_velocity_pair = [&]() __attribute__((always_inline)) {
-        const float vx6 = vx, vz6 = vz, om6 = om;  // (what stage (5) left — only the averaged form reads them again)
-        const f2 rcx = mk2(cposx[0], cposx[J1]) - bc2(px), rcz = mk2(cposz[0], cposz[J1]) - bc2(pz);
-        const f2 vptx = fma2(bc2(om), rcz, bc2(vx)), vptz = fma2(bc2(-om), rcx, bc2(vz));
+      float vx6 = 0.0f, vz6 = 0.0f, om6 = 0.0f;  // what stage (5) left: every pair of the link computes from these
+      auto resolve_velocity_pair = [&](auto pair_tag) __attribute__((always_inline)) {
+        constexpr int Q = decltype(pair_tag)::value, C0 = MAXCOL > 1 ? 2 * Q : 0, C1 = MAXCOL > 1 ? 2 * Q + 1 : 0;
+        if constexpr (Q == 0) { vx6 = vx; vz6 = vz; om6 = om; }
+        const f2 rcx = mk2(cposx[C0], cposx[C1]) - bc2(px), rcz = mk2(cposz[C0], cposz[C1]) - bc2(pz);
+        const f2 vptx = fma2(bc2(om6), rcz, bc2(vx6)), vptz = fma2(bc2(-om6), rcx, bc2(vz6));
         f2 vn_prev = bc2(0.0f);
         if (FL >= 0 ? (FL & 4) != 0 : elast != 0.0f) vn_prev = fma2(bc2(-om_old), rcx, bc2(vz_old));  // (wave-uniform; with e = 0 the term is exactly 0)
         const f2 vtn = __builtin_elementwise_abs(vptx);
@@ -475,7 +480,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         const f2 wt = fma2(rcz, rcz * bc2(iy_c), bc2(im_c));
         const f2 rest = bc2(-elast) * vn_prev;
         const f2 dvn = (sp_rmin ? mk2(fmin_(rest.x, 0.0f), fmin_(rest.y, 0.0f)) : mk2(fmax_(rest.x, 0.0f), fmax_(rest.y, 0.0f))) - vptz;
-        const f2 jt_max = (bc2(mu) * mk2(cdlam[0], cdlam[J1])) * bc2(inv_dt);
+        const f2 jt_max = (bc2(mu) * mk2(cdlam[C0], cdlam[C1])) * bc2(inv_dt);
         const f2 jw = sp_fvel ? jt_max : jt_max * wt;
         const f2 dvt = mk2(fmin_(jw.x, vtn.x), fmin_(jw.y, vtn.y));
         f2 q_n, q_t;
@@ -483,15 +488,15 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         const f2 Pix = mk2(-__builtin_copysignf(q_t.x, vptx.x), -__builtin_copysignf(q_t.y, vptx.y)), Piz = q_n;  // friction opposes the slip
         const f2 dom = pl_cross2(rcx, rcz, Pix, Piz) * bc2(iy_c);
         const float nvx0 = ffma(im_c, Pix.x, vx), nvz0 = ffma(im_c, Piz.x, vz), nom0 = om + dom.x;
-        vx = cact[0] ? nvx0 : vx; vz = cact[0] ? nvz0 : vz; om = cact[0] ? nom0 : om;
+        vx = cact[C0] ? nvx0 : vx; vz = cact[C0] ? nvz0 : vz; om = cact[C0] ? nom0 : om;
         float nvx1 = ffma(im_c, Pix.y, vx), nvz1 = ffma(im_c, Piz.y, vz), nom1 = om + dom.y;
         // (EO: the three stay SELECTS — left alone the compiler sinks them under an EXEC mask, and one divergent region anywhere
         // makes it linearise the early-out's uniform if / else through flag registers: a second branch on the common path)
         if constexpr (EO) asm volatile("" : "+v"(nvx1), "+v"(nvz1), "+v"(nom1));
-        vx = cact[J1] ? nvx1 : vx; vz = cact[J1] ? nvz1 : vz; om = cact[J1] ? nom1 : om;
-        if constexpr (SPEC_AVG) {
+        vx = cact[C1] ? nvx1 : vx; vz = cact[C1] ? nvz1 : vz; om = cact[C1] ? nom1 : om;
+        if constexpr (SPEC_AVG && MAXCOL == 2) {
           if (sp_avg) {  // both touch: the average of the link's two velocity changes, v6 + (v - v6) / 2
-            const bool both = cact[0] && cact[J1];
+            const bool both = cact[C0] && cact[C1];
             vx = both ? ffma(vx - vx6, 0.5f, vx6) : vx;
             vz = both ? ffma(vz - vz6, 0.5f, vz6) : vz;
             om = both ? ffma(om - om6, 0.5f, om6) : om;
@@ -500,48 +505,56 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       };
       {
         float cdx = 0.0f, cdz = 0.0f, cdth = 0.0f;
-        if constexpr (MAXCOL == 2) {
-          // both colliders of the link as one packed pair (the solve is Jacobi: each sees the pose of the stage's
-          // start); their corrections are then added in collider order
+        if constexpr (MAXCOL == 2 || MAXCOL == 4) {
+          // the link's colliders as packed PAIRS (0, 1) and, MAXCOL = 4, (2, 3) (the solve is Jacobi: each sees the pose of the
+          // stage's start); their corrections are then added in collider order
+          constexpr int NP = MAXCOL / 2;
           const PCs a = pl_cs(qw, qy);
-          const f2 cx2 = mk2(colx[0], colx[1]), cz2 = mk2(colz[0], colz[1]), rad2 = mk2(col_rad[0], col_rad[1]);
-          const f2 offx = fma2(bc2(a.s), cz2, bc2(a.c) * cx2), offz = fma2(bc2(-a.s), cx2, bc2(a.c) * cz2);
-          const f2 ctrx = bc2(px) + offx, ctrz = bc2(pz) + offz;
-          const f2 pen = rad2 - ctrz;
-          const bool act0 = col_has[0] && pen.x > 0.0f, act1 = col_has[1] && pen.y > 0.0f;
+          f2 cx2[NP], cz2[NP], rad2[NP], offx[NP], offz[NP], ctrx[NP], ctrz[NP], pen[NP];
+          bool act0[NP], act1[NP];
+#pragma unroll
+          for (int q = 0; q < NP; ++q) {
+            cx2[q] = mk2(colx[2 * q], colx[2 * q + 1]); cz2[q] = mk2(colz[2 * q], colz[2 * q + 1]);
+            rad2[q] = mk2(col_rad[2 * q], col_rad[2 * q + 1]);
+            offx[q] = fma2(bc2(a.s), cz2[q], bc2(a.c) * cx2[q]); offz[q] = fma2(bc2(-a.s), cx2[q], bc2(a.c) * cz2[q]);
+            ctrx[q] = bc2(px) + offx[q]; ctrz[q] = bc2(pz) + offz[q];
+            pen[q] = rad2[q] - ctrz[q];
+            act0[q] = col_has[2 * q] && pen[q].x > 0.0f; act1[q] = col_has[2 * q + 1] && pen[q].y > 0.0f;
+          }
           // the rest of the stage: everything it changes sits behind act0 / act1
-          auto resolve_position_pair = [&]() __attribute__((always_inline)) {
+          auto resolve_position_pair = [&](auto pair_tag) __attribute__((always_inline)) {
+            constexpr int Q = decltype(pair_tag)::value;
             const PCs ap = pl_cs(qwp, qyp);
-            const f2 h = fma2(bc2(-0.5f), pen, rad2);
-            const f2 posx = ctrx, posz = ctrz - h;
-            const f2 rcx = offx, rcz = offz - h;
+            const f2 h = fma2(bc2(-0.5f), pen[Q], rad2[Q]);
+            const f2 posx = ctrx[Q], posz = ctrz[Q] - h;
+            const f2 rcx = offx[Q], rcz = offz[Q] - h;
             const f2 icn = rcx * bc2(iy_c);
             const f2 wn = fma2(icn, rcx, bc2(im_c));
             const f2 d = -h;
-            const f2 rlx = fma2(bc2(-a.s), d, cx2), rlz = fma2(bc2(a.c), d, cz2);
+            const f2 rlx = fma2(bc2(-a.s), d, cx2[Q]), rlz = fma2(bc2(a.c), d, cz2[Q]);
             const f2 pprevx = bc2(pxp) + fma2(bc2(ap.s), rlz, bc2(ap.c) * rlx);
             const f2 ddx = posx - pprevx;
             // static friction: the tangent is the x axis, |d|^2 / (d.W d) of the 3-D form is 1 / (im + rcz^2 iy)
             const f2 wt = fma2(rcz, rcz * bc2(iy_c), bc2(im_c));
             f2 q_n, q_g;
-            div2x2_(pen, wn, bc2(1.0f), wt, q_n, q_g);
+            div2x2_(pen[Q], wn, bc2(1.0f), wt, q_n, q_g);
             const f2 dlam = q_n * bc2(coll_scale), sx = q_g * ddx;
             const f2 lim = bc2(mu) * dlam;
             const f2 lhs = sx * sx, rhs = lim * lim;
             const f2 Pix = mk2(lhs.x < rhs.x ? -sx.x : 0.0f, lhs.y < rhs.y ? -sx.y : 0.0f), Piz = dlam;
             const f2 dth = pl_cross2(rcx, rcz, Pix, Piz) * bc2(iy_c);
-            cdx = act0 ? ffma(im_c, Pix.x, cdx) : cdx;
-            cdz = act0 ? ffma(im_c, Piz.x, cdz) : cdz;
-            cdth = act0 ? cdth + dth.x : cdth;
-            cdx = act1 ? ffma(im_c, Pix.y, cdx) : cdx;
-            cdz = act1 ? ffma(im_c, Piz.y, cdz) : cdz;
-            cdth = act1 ? cdth + dth.y : cdth;
-            if constexpr (!SPEC && (MBD_TUNED_SPEC & MBD_FLAG_CONTACT_AVG) != 0) {  // both touch: half the summed correction
-              const bool both = act0 && act1;                                        // (SPEC: averaged below, like any MAXCOL)
+            cdx = act0[Q] ? ffma(im_c, Pix.x, cdx) : cdx;
+            cdz = act0[Q] ? ffma(im_c, Piz.x, cdz) : cdz;
+            cdth = act0[Q] ? cdth + dth.x : cdth;
+            cdx = act1[Q] ? ffma(im_c, Pix.y, cdx) : cdx;
+            cdz = act1[Q] ? ffma(im_c, Piz.y, cdz) : cdz;
+            cdth = act1[Q] ? cdth + dth.y : cdth;
+            if constexpr (!SPEC && MAXCOL == 2 && (MBD_TUNED_SPEC & MBD_FLAG_CONTACT_AVG) != 0) {  // both touch: half the summed correction
+              const bool both = act0[Q] && act1[Q];  // (SPEC, and four colliders: averaged below over the link's count)
               cdx = both ? cdx * 0.5f : cdx; cdz = both ? cdz * 0.5f : cdz; cdth = both ? cdth * 0.5f : cdth;
             }
-            cposx[0] = posx.x; cposx[J1] = posx.y; cposz[0] = posz.x; cposz[J1] = posz.y;
-            cdlam[0] = dlam.x; cdlam[J1] = dlam.y; cact[0] = act0; cact[J1] = act1;
+            cposx[2 * Q] = posx.x; cposx[2 * Q + 1] = posx.y; cposz[2 * Q] = posz.x; cposz[2 * Q + 1] = posz.y;
+            cdlam[2 * Q] = dlam.x; cdlam[2 * Q + 1] = dlam.y; cact[2 * Q] = act0[Q]; cact[2 * Q + 1] = act1[Q];
           };
           if constexpr (EO) {
             // WAVE-UNIFORM early-out: no sphere of any lane is below the plane.  What remains of stages (4) - (6) then:
@@ -551,7 +564,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
             // (a) it is ONE compare into vcc — the larger of the two penetrations, with -inf radii on the lanes that lack a
             // collider: no scalar mask arithmetic — and (b) the common side's pose update is computed between the compare
             // and the branch, where it is free (the side that has a contact discards it).
-            const f2 penb = radb2 - ctrz;
+            const f2 penb = radb2 - ctrz[0];
             const bool touching = __builtin_amdgcn_fcmpf(fmax_(penb.x, penb.y), 0.0f, 2 /* ogt */) != 0ull;
             __builtin_amdgcn_sched_barrier(0);
             float fpx = px + cdx, fpz = pz + cdz, fqw = qw, fqy = qy;
@@ -562,14 +575,15 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
               px = fpx; pz = fpz; qw = fqw; qy = fqy;
               project_xd();
             } else {
-              resolve_position_pair();
+              resolve_position_pair(std::integral_constant<int, 0>{});
               px = px + cdx; pz = pz + cdz;
               pl_qupdate<true, QM>(qw, qy, cdth, q_worst);
               project_xd();
-              resolve_velocity_pair();
+              resolve_velocity_pair(std::integral_constant<int, 0>{});
             }
           } else {
-            resolve_position_pair();
+            resolve_position_pair(std::integral_constant<int, 0>{});
+            if constexpr (MAXCOL == 4) resolve_position_pair(std::integral_constant<int, 1>{});
           }
         } else         if constexpr (MAXCOL > 0) {
           const PCs a = pl_cs(qw, qy), ap = pl_cs(qwp, qyp);
@@ -601,7 +615,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
             cposx[j] = posx; cposz[j] = posz; cdlam[j] = dlam; cact[j] = active;
           }
         }
-        if constexpr (SPEC && MAXCOL > 0) {
+        if constexpr (SPEC_AVG && MAXCOL > 0 && (SPEC || MAXCOL != 2)) {  // (tuned, two colliders: averaged inside the pair above)
           if (sp_avg) {  // the average over the link's active contacts (two or more; one: untouched)
             int n_act = 0;
 #pragma unroll
@@ -621,10 +635,24 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
       // order (SPEC, contact6_gauss_seidel: one after the other, each from the running values)
       if constexpr (EO) {
         // (done above, on the path that had a contact)
-      } else if constexpr (MAXCOL == 2 && !SPEC && !TUNED_GS) {
-        resolve_velocity_pair();
+      } else if constexpr ((MAXCOL == 2 || MAXCOL == 4) && !SPEC && !TUNED_GS) {
+        resolve_velocity_pair(std::integral_constant<int, 0>{});
+        if constexpr (MAXCOL == 4) {
+          resolve_velocity_pair(std::integral_constant<int, 1>{});
+          if constexpr (SPEC_AVG) {
+            if (sp_avg) {  // the average of the link's velocity changes over its active contacts: v6 + (v - v6) / n
+              int n_act = 0;
+#pragma unroll
+              for (int j = 0; j < MAXCOL; ++j) n_act += cact[j] ? 1 : 0;
+              const float inv_n = 1.0f / (float)(n_act > 1 ? n_act : 1);
+              vx = n_act >= 2 ? ffma(vx - vx6, inv_n, vx6) : vx;
+              vz = n_act >= 2 ? ffma(vz - vz6, inv_n, vz6) : vz;
+              om = n_act >= 2 ? ffma(om - om6, inv_n, om6) : om;
+            }
+          }
+        }
       } else if constexpr (MAXCOL > 0) {
-        const float vx6 = vx, vz6 = vz, om6 = om;  // what every contact of the link sees
+        vx6 = vx; vz6 = vz; om6 = om;  // what every contact of the link sees
 #pragma unroll
         for (int j = 0; j < MAXCOL; ++j) {
           const float rcx = cposx[j] - px, rcz = cposz[j] - pz;

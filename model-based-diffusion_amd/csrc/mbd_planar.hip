@@ -22,6 +22,16 @@ bool planar_has_early_out(int lps, int dpp_family, int max_col, int fl, int rk, 
 hipError_t launch_rollout_planar(int lps, int dpp_family, int max_col, int fl, int rk, int nfr, bool no_fl, bool spec, int device,
                                  dim3 grid, dim3 block, size_t lds, hipStream_t stream, const RolloutParams& P) {
 #define PL(...) return launch_rollout_kernel(rollout_planar_kernel<__VA_ARGS__>, device, grid, block, lds, stream, P)
+  if (max_col > 2) {  // three or four spheres on a link (round 6: collide_all_capsules puts four on the halfcheetah's torso)
+    if (spec) PL(16, 4, 0, 0, -1, -1, 0, true);
+    if (lps == 8 && dpp_family == 1) {
+      if (fl == 1 && rk == MBD_REW_HALFCHEETAH && !no_fl && nfr == 16) PL(8, 4, 1, -3, 1, MBD_REW_HALFCHEETAH, 16);
+      PL(8, 4, 1, -3);
+    }
+    if (lps == 4) PL(4, 4, 0, 0);
+    if (lps == 8) PL(8, 4, 0, 0);
+    PL(16, 4, 0, 0);
+  }
   if (spec) PL(16, 2, 0, 0, -1, -1, 0, true);  // specification switches at run time
 #if (MBD_TUNED_SPEC & 8) == 0
   if (P.cpw > 0) {  // (the launch geometry asked planar_has_early_out first)

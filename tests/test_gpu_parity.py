@@ -1428,11 +1428,12 @@ def test_demo_log_density_accumulated_in_the_rollout_is_bit_identical(gpu, orc_o
     assert np.array_equal(got, want)
 
 
-@pytest.mark.parametrize("name,planar_expected", [("hopper", True), ("walker2d", True), ("halfcheetah", False)])
+@pytest.mark.parametrize("name,planar_expected", [("hopper", True), ("walker2d", True), ("halfcheetah", True)])
 def test_collide_all_capsules_models_bitexact(gpu, orc_omp, name, planar_expected):
     """DESIGN.md §9's data-level switch `collide_all_capsules` (every capsule end of every link a sphere collider instead of the
     feet only): hopper and walker2d stay on the tuned planar kernels (two spheres per link, now on EVERY lane), the
-    halfcheetah's torso carries four and runs the general 3-D instantiation — rollouts and a short plan bit for bit the checker's."""
+    halfcheetah's torso carries four and runs the planar kernels' four-collider instantiation (MAXCOL = 4: the stages collider by
+    collider) — rollouts and a short plan bit for bit the checker's."""
     from conftest import ROOT
     from mbd_hip import mjcf
     from mbd_hip.envs import specs
@@ -1751,9 +1752,19 @@ from mbd_hip import _capi
 from mbd_hip.envs.base import RigidBodyEnv
 from mbd_hip.planners.mbd_planner import Args, Plan
 res = {"lib": np.array(os.environ.get("MBD_HIP_LIB", "")), "tuned": np.array(_capi.load().mbd_tuned_spec())}
+def model_of(name, bits):
+    if name.endswith("CA"):  # collide_all_capsules: the halfcheetah's torso then carries FOUR spheres (mbd_planar.h MAXCOL = 4)
+        from mbd_hip import mjcf
+        from mbd_hip.envs import specs
+        sp = specs.SPECS[name[:-2]]
+        return mjcf.load(os.path.join(pkg, "assets", sp["xml"]), env_name=name[:-2], n_frames=sp["n_frames"], reset_noise=sp["reset_noise"],
+                         reward_params=sp.get("reward_params", ()), gear_override=sp.get("gear_override", ()), collide_all_capsules=True,
+                         warn_unstable=False, spec_flags=bits)
+    return load_model(name).with_spec(bits)
 for name, B, bits in (("hopper", 80, W), ("halfcheetah", 72, W), ("walker2d", 40, W), ("ant", 44, W), ("humanoidstandup", 36, W),
-                      ("humanoidrun", 48, W), ("ant", 4200, W), ("hopper", 64, 0), ("humanoidstandup", 24, 0), ("hopper", 48, W ^ 16)):
-    env = RigidBodyEnv(name, model=load_model(name).with_spec(bits))
+                      ("humanoidrun", 48, W), ("ant", 4200, W), ("hopper", 64, 0), ("humanoidstandup", 24, 0), ("hopper", 48, W ^ 16),
+                      ("halfcheetahCA", 56, W), ("halfcheetahCA", 40, 0)):
+    env = RigidBodyEnv(name.replace("CA", ""), model=model_of(name, bits))
     st = env.reset(_capi.prng_key(5))
     H = 50 if B < 1000 else 6
     us = np.clip(np.random.default_rng(B + bits).normal(size=(B, H, env.action_size)) * 0.5, -1.2, 1.2).astype(np.float32)
@@ -1806,10 +1817,19 @@ def test_tuned_spec_variant_is_bit_exact_to_the_flagged_checker(gpu, orc_omp, tm
     res = np.load(out)
     assert str(res["lib"]).endswith(lib_name) and int(res["tuned"]) == word
     cases = sorted({k.rsplit("_", 1)[0] for k in res.files if k.endswith("_rewss")})
-    assert len(cases) == 10
+    assert len(cases) == 12
     for c in cases:
         name, B, bits = c.split("_")
-        m = load_model(name).with_spec(int(bits))
+        if name.endswith("CA"):
+            from mbd_hip import mjcf
+            from mbd_hip.envs import specs
+            sp = specs.SPECS[name[:-2]]
+            m = mjcf.load(os.path.join(pkg, "assets", sp["xml"]), env_name=name[:-2], n_frames=sp["n_frames"], reset_noise=sp["reset_noise"],
+                          reward_params=sp.get("reward_params", ()), gear_override=sp.get("gear_override", ()), collide_all_capsules=True,
+                          warn_unstable=False, spec_flags=int(bits))
+            name = name[:-2]
+        else:
+            m = load_model(name).with_spec(int(bits))
         oe = OracleEnv(orc_omp, name, m.to_struct(), init_q=getattr(m, "init_q", None))
         ref = oe.rollout(res[c + "_state"], res[c + "_us"])
         assert np.isfinite(res[c + "_rewss"]).all() and np.array_equal(res[c + "_rewss"], ref), c
