@@ -5,7 +5,7 @@ Data-level guesses live here as keys a golden vector can flip, r
       files from inside its wheel; the re-authored ones give only the FEET a contype (hopper.xml: foot_geom), so a body that
       tips over sinks its torso through the floor and keeps collecting forward reward (tools/model_guess_report.py: how often).
       True makes every capsule of every link collide (ends as spheres); hopper / walker2d stay on the planar kernels (two
-      spheres per link), the halfcheetah's torso then carries four and compiles as a 3-D model.
+      spheres per link), the halfcheetah's torso then carries four (the planar kernels' four-collider instantiations).
 """
 
 SPECS = {

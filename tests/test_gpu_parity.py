@@ -1490,6 +1490,60 @@ def test_speculated_renormalisation_reruns_the_control_step_exactly(gpu, orc, na
     levers(MBD_CPW=-1)
 
 
+@pytest.mark.parametrize("which,no_dpp,general", [("hopper", 0, 0), ("hopper", 1, 0), ("halfcheetah", 0, 0), ("halfcheetah", 1, 0),
+                                                  ("halfcheetah", 0, 1), ("tripod", 0, 0)])
+def test_planar_links_with_three_or_four_colliders(gpu, orc_omp, which, no_dpp, general, levers):
+    """Round 6: the planar kernels take up to FOUR sphere colliders per link (MAXCOL = 4: two packed pairs) — what
+    collide_all_capsules gives the halfcheetah's torso.  Every instantiation of that form: 4-lane groups (the hopper with two more
+    spheres on its foot and one more on its leg), 8-lane DPP / shuffle / run-time switches (the halfcheetah with every capsule
+    colliding), 16-lane groups (the ten-link tripod with three spheres on one link); rollouts bit for bit the checker's."""
+    from conftest import ROOT
+    from custom_models import TRIPOD
+    from test_oracle_physics import _compile
+    from mbd_hip import mjcf
+    from mbd_hip.envs import specs
+    from mbd_hip.envs.base import RigidBodyEnv
+    from oracle.planner import OracleEnv
+    if no_dpp:
+        levers(MBD_NO_DPP=1)
+    if general:
+        for k in ("MBD_NO_PLANAR_FLAGS", "MBD_NO_REWARD_CONST", "MBD_NO_NFR_CONST"):
+            levers(**{k: 1})
+    assets = os.path.join(ROOT, "model-based-diffusion_amd", "assets")
+    if which == "halfcheetah":
+        sp = specs.SPECS["halfcheetah"]
+        m = mjcf.load(os.path.join(assets, sp["xml"]), env_name="halfcheetah", n_frames=sp["n_frames"], reset_noise=sp["reset_noise"],
+                      reward_params=sp["reward_params"], gear_override=sp["gear_override"], collide_all_capsules=True, warn_unstable=False)
+        name, want_max = "halfcheetah", 4
+    elif which == "hopper":
+        xml = open(os.path.join(assets, "hopper.xml")).read()
+        xml = xml.replace('name="foot_geom" size="0.06" type="capsule"/>', 'name="foot_geom" size="0.06" type="capsule"/>'
+                          '<geom contype="1" type="sphere" pos="0.06 0 0" size="0.07"/><geom contype="1" type="sphere" pos="0.2 0 0" size="0.065"/>')
+        xml = xml.replace('name="leg_geom" size="0.04" type="capsule"/>', 'name="leg_geom" size="0.04" type="capsule" contype="1"/>'
+                          '<geom contype="1" type="sphere" pos="0 0 -0.25" size="0.05"/>')
+        assert xml.count('type="sphere"') == 3
+        sp = specs.SPECS["hopper"]
+        m = _compile(xml, env_name="hopper", n_frames=sp["n_frames"], reset_noise=sp["reset_noise"], reward_params=sp["reward_params"])
+        name, want_max = "hopper", 4
+    else:
+        # (foot_a: its capsule's two end spheres plus one on the capsule's axis — the link stays diagonal in its own frame)
+        xml = TRIPOD.replace('<geom contype="1" fromto="-0.05 0 0 0.15 0 0" size="0.05" type="capsule"/>',
+                             '<geom contype="1" fromto="-0.05 0 0 0.15 0 0" size="0.05" type="capsule"/>'
+                             '<geom contype="1" type="sphere" pos="0.05 0 0" size="0.06"/>')
+        assert xml != TRIPOD
+        m = _compile(xml, env_name="halfcheetah", n_frames=6, reset_noise=0.05, reward_params=(1.0, 0.1))
+        name, want_max = "halfcheetah", 3
+    cl = list(m.fields["col_link"][:int(m.fields["n_col"])])
+    assert bool(int(m.fields["flags"]) & 2) and max(cl.count(l) for l in set(cl)) >= min(want_max, 3)
+    env = RigidBodyEnv(name, model=m)
+    oe = OracleEnv(orc_omp, name, m.to_struct(), init_q=m.init_q)
+    st = env.reset(gpu.prng_key(8))
+    us = np.clip(np.random.default_rng(11).normal(size=(53, 40, env.action_size)) * 0.7, -1.2, 1.2).astype(np.float32)
+    ref = oe.rollout(np.asarray(st.pipeline_state, np.float32), us)
+    got = env.rollout(st, us).cpu().numpy()
+    assert np.isfinite(got).all() and np.ptp(got) > 1e-3 and np.array_equal(got, ref), np.abs(got - ref).max()
+
+
 # ---- two candidates per lane (mbd_pk2.h) -----------------------------------------------------------------------------
 @pytest.mark.parametrize("name,B,H,sigma", [("humanoidrun", 96, 50, 0.6), ("humanoidrun", 1, 3, 0.3),
                                             ("humanoidrun", 37, 20, 0.9), ("humanoidtrack", 64, 50, 0.4),
