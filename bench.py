@@ -231,7 +231,7 @@ def parity_vs_jax(ref, cfg, versions, last_run):
     from the reset pose and from a settled pose, the bounce — against this repo's checker (tools/compare_golden.py):
       first_mismatch_stage   the first stage of Brax's substep the DEFAULT specification misses by more than 1e-5 (null: none),
       fitted_flags / fitted  the word of DESIGN.md §9's switches that fits best (--search) and its names: a word other than this
-                             build's mbd_tuned_spec() is answered by the variant library of that word (libmbd_hip_avg.so = 4),
+                             build's mbd_tuned_spec() (4 = contact_avg as shipped) is answered by the variant library of that word (libmbd_hip_sum.so = 0),
       max_rel                teacher-forced: the checker's rewards on the reference's candidates of those steps vs Brax's
                              (the north star's 1e-5), per quantity in max_rel_rewards / max_rel_ybar,
       rew_final_ref          what the reference's last timed run_diffusion returned (seed 0, its Ndiffuse beside it; main() adds
@@ -267,7 +267,7 @@ def parity_vs_jax(ref, cfg, versions, last_run):
             if first is not None:
                 out["first_mismatch"] = {"stage": first[0], "link": int(first[1]), "quantity": first[2], "err": float(first[3])}
             best = rows[0]
-            out["fitted_flags"], out["fitted"] = int(best[0]), list(best[1]) or ["default"]
+            out["fitted_flags"], out["fitted"] = int(best[0]), list(best[1]) or ["none"]
             out["fitted_first_mismatch_stage"] = None if best[2] is None else best[2][0]
             out["report"] = lines[-12:]
         # record (A), teacher-forced through the checker (the cpu_baseline leg may use it)
@@ -276,7 +276,9 @@ def parity_vs_jax(ref, cfg, versions, last_run):
         orc_mod.build()
         orc = orc_mod.Oracle("f32")
         with open(os.path.join(ROOT, "model-based-diffusion_amd", "assets", "compiled", f"{cfg['env']}.json")) as f:
-            m = Model.from_json(f.read()).with_spec(out.get("fitted_flags", 0) if out.get("fitted_first_mismatch_stage", 1) is None else 0)
+            m = Model.from_json(f.read())   # (as compiled: the default word)
+        if "fitted_flags" in out and out.get("fitted_first_mismatch_stage", 1) is None:
+            m = m.with_spec(out["fitted_flags"])
         ms = m.to_struct()
         st = orc.forward(ms, np.asarray(g["q0"], np.float32), np.asarray(g["qd0"], np.float32))
         er, ey = 0.0, 0.0

@@ -78,13 +78,20 @@ enum mbd_model_flags {
                                   plane over a rollout.  Set by mbd_hip/mjcf.py when the model qualifies (planar=False
                                   keeps the 3-D path); a specification of its own for these models. */
   /* ---- SPECIFICATION SWITCHES: the places where this engine had to guess at CODE level what Brax's positional
-   * pipeline does.  Default 0 = the specification the tuned kernels compile in; each bit selects the named
-   * alternative, in the checker and in the kernels alike (bit-exact against each other either way), so that a golden
-   * vector of the real reference flips a flag instead of forcing a rewrite (tools/compare_golden.py --search tries every
-   * combination).  Models with any of these bits run the general `spec` kernel instantiations (not the tuned ones). */
+   * pipeline does.  Each bit selects the named form, in the checker and in the kernels alike (bit-exact
+   * against each other either way), so that a golden vector of the real reference flips a flag instead of forcing a rewrite
+   * (tools/compare_golden.py --search tries every combination).  The DEFAULT word is MBD_DEFAULT_SPEC (below): what
+   * mbd_hip.mjcf.load gives a model, what the built-in models carry and what the shipped library's tuned kernels compile in
+   * (mbd_tuned_spec()); a model with another word runs the general `spec` kernel instantiations. */
   MBD_FLAG_CONTACT_AVG = 4,        /* several ACTIVE contacts on one link: the link's position correction (stage 4) and —
                                       unless CONTACT6_GAUSS_SEIDEL — its velocity change (stage 6) are the AVERAGE over
-                                      them (sum * 1/n, n >= 2) instead of the sum; single contacts are untouched          */
+                                      them (sum * 1/n, n >= 2) instead of the sum; single contacts are untouched.
+                                      SET BY DEFAULT since round 6: contacts solved independently (Jacobi, below) and
+                                      SUMMED blow up when a link's contacts sit close to its centre of mass — four
+                                      spheres 1 cm around it turn -0.5 m/s into -9.5 m/s in ONE substep
+                                      (tests/test_oracle_invariants.py) — so an engine that vmaps its contacts has to
+                                      average them (Brax v1's colliders divided by the contact count); bit clear: the
+                                      sum of rounds 1-5                                                                    */
   MBD_FLAG_CONTACT6_GAUSS_SEIDEL = 8, /* stage (6), collisions.resolve_velocity.  DEFAULT (bit clear, since round 5): every
                                       contact of a link computes its impulse from the SAME velocities (those stage (5)
                                       left) and the changes are added in collider order (Jacobi) — the only form Brax's code
@@ -105,6 +112,7 @@ enum mbd_model_flags {
                                       which ignore the bit                                                                */
 };
 #define MBD_SPEC_FLAGS (4 | 8 | 16 | 32 | 64 | 128)
+#define MBD_DEFAULT_SPEC 4 /* Jacobi per link + average over a link's active contacts */
 
 typedef struct mbd_model {
   /* sizes */
@@ -173,7 +181,7 @@ const char* mbd_last_error(void);
 int mbd_version(void);
 /* The word of specification switches (mbd_model_flags, MBD_SPEC_FLAGS) this BUILD's tuned kernels compile in: models whose
  * switches equal it run them, any other word runs the general instantiations that read the switches per launch (same results,
- * a third to a half of the speed).  0 in the shipped library; -DMBD_TUNED_SPEC=<word> rebuilds it (no
+ * a third to a half of the speed).  MBD_DEFAULT_SPEC in the shipped library; -DMBD_TUNED_SPEC=<word> rebuilds it (no
  * counterpart in the reference, whose physics has ONE specification — Brax's, which no vector pins yet). */
 int mbd_tuned_spec(void);
 /* number of usable gfx950 devices (0 on a box without a GPU — every compute entry then returns

@@ -25,14 +25,14 @@
 #include "../../include/mbd_hip.h"
 #include "mbd_math.h"
 
-// The specification the TUNED instantiations compile in: a word of mbd_model_flags' switches, 0 in the shipped
-// library.  A model whose switches equal it runs the tuned kernels; any other word runs the general SPEC instantiations, which
+// The specification the TUNED instantiations compile in: a word of mbd_model_flags' switches, MBD_DEFAULT_SPEC
+// (contact_avg) in the shipped library.  A model whose switches equal it runs the tuned kernels; any other word runs the general SPEC instantiations, which
 // read the switches at run time — at a third to a half of the speed (profiles/r06_spec_cost.txt).  So the day a golden vector of
 // Brax decides a switch the other way, the answer is a REBUILD with -DMBD_TUNED_SPEC=<word> (tools/build_variant.py; build()
-// keeps lib/variants/libmbd_hip_avg.so = contact_avg, the likeliest, held bit-exact to the flagged checker by the GPU suite).
+// keeps lib/variants/libmbd_hip_sum.so = word 0, the summed contacts of rounds 1-5, held bit-exact to the checker by the GPU suite).
 // Switches the tuned kernels can compile in: contact_avg, contact6_gauss_seidel, friction_vel_bound, restitution_min.
 #ifndef MBD_TUNED_SPEC
-#define MBD_TUNED_SPEC 0
+#define MBD_TUNED_SPEC MBD_DEFAULT_SPEC
 #endif
 static_assert((MBD_TUNED_SPEC & ~(MBD_FLAG_CONTACT_AVG | MBD_FLAG_CONTACT6_GAUSS_SEIDEL | MBD_FLAG_FRICTION_VEL_BOUND | MBD_FLAG_RESTITUTION_MIN)) == 0,
               "MBD_TUNED_SPEC: euler_extrinsic and gyroscopic exist in the SPEC instantiations only");

@@ -25,7 +25,7 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-from .model import (MAX_ACT, MAX_COL, MAX_LINKS, MAX_Q, MAX_TRACK, Model, REWARD_KINDS, SPEC_MASK)
+from .model import (DEFAULT_SPEC, MAX_ACT, MAX_COL, MAX_LINKS, MAX_Q, MAX_TRACK, Model, REWARD_KINDS, SPEC_MASK)
 
 # defaults of brax.io.mjcf.load for <custom><numeric> entries that are absent (recollection)
 _CUSTOM_DEFAULTS = {
@@ -326,7 +326,7 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
          reward_params: Sequence[float] = (), dt_override: Optional[float] = None,
          init_q_offset: Sequence[float] = (), gear_override: Sequence[float] = (),
          passive_joint_forces: bool = True, reset_quat_raw: bool = False, planar: Optional[bool] = None,
-         spec_flags: int = 0, warn_unstable: bool = True, collide_all_capsules: bool = False) -> Model:
+         spec_flags: Optional[int] = None, warn_unstable: bool = True, collide_all_capsules: bool = False) -> Model:
     """Compile an MJCF file. ``n_frames`` is the env's physics substeps per control step
     (humanoidrun.py:17 -> 7, humanoidtrack.py:46 -> 5, hopper.py:18 -> 20).
 
@@ -341,7 +341,9 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
                             the general 3-D arithmetic for a planar model.
       spec_flags            the CODE-level guesses as flag bits (model.SPEC_FLAGS / model.spec_bits: contact_avg,
                             contact6_gauss_seidel, friction_vel_bound, restitution_min, euler_extrinsic, gyroscopic;
-                            include/mbd_hip.h mbd_model_flags): checker and kernels honour them alike.
+                            include/mbd_hip.h mbd_model_flags): checker and kernels honour them alike.  None: the default
+                            word, model.DEFAULT_SPEC (contact_avg since round 6) — what the shipped library's tuned
+                            kernels compile in; any other word runs the general kernels.
       collide_all_capsules  a DATA-level guess about the re-authored hopper / walker2d / halfcheetah files (Brax ships its own
                             in its wheel): False — only the geoms whose contype / conaffinity meet the floor's collide (the
                             FEET in those files: a body that tips over sinks through the floor and keeps collecting its
@@ -592,7 +594,7 @@ def load(path: str, env_name: str = "", n_frames: int = 1, drop_link_suffix: Opt
         n_links=L, n_q=nq, n_qd=nqd, n_act=len(act_link), n_col=len(col_link), n_track=len(track),
         n_frames=int(n_frames), reward_kind=REWARD_KINDS.get(env_name, 0), iso_inertia=int(iso),
         # (MBD_FLAG_PLANAR is added below, once the model is complete; spec_flags: the specification switches, model.SPEC_FLAGS)
-        flags=int(1 if reset_quat_raw else 0) | (int(spec_flags) & SPEC_MASK),
+        flags=int(1 if reset_quat_raw else 0) | (int(DEFAULT_SPEC if spec_flags is None else spec_flags) & SPEC_MASK),
         dt=np.float32(dt), vel_fac=np.float32(math.exp(custom["vel_damping"] * dt)),
         ang_fac=np.float32(math.exp(custom["ang_damping"] * dt)),
         joint_scale_pos=np.float32(custom["joint_scale_pos"]),

@@ -28,6 +28,8 @@ FLAG_RESET_QUAT_RAW, FLAG_PLANAR = 1, 2
 SPEC_FLAGS = {"contact_avg": 4, "contact6_gauss_seidel": 8, "friction_vel_bound": 16, "restitution_min": 32,
               "euler_extrinsic": 64, "gyroscopic": 128}
 SPEC_MASK = sum(SPEC_FLAGS.values())
+# the default word (include/mbd_hip.h MBD_DEFAULT_SPEC): what mjcf.load gives a model and the shipped library's tuned kernels compile in
+DEFAULT_SPEC = SPEC_FLAGS["contact_avg"]
 
 
 def spec_bits(*names: str) -> int:

@@ -124,7 +124,7 @@ def test_parity_jax_object_from_a_dump(bench_mod, orc, tmp_path, monkeypatch):
     import dump_golden
     from conftest import load_model
     from test_golden import _synthetic_stage_file
-    planted = 8   # ("Brax" = the checker with stage (6) Gauss-Seidel)
+    planted = 12   # ("Brax" = the checker with stage (6) Gauss-Seidel on top of the default word, contact_avg)
 
     def fake_dump(ref, env_name, N, H, steps, out_dir=".", records="ABC"):
         path = os.path.join(out_dir, f"golden_{env_name}_N{N}_H{H}.npz")
@@ -145,7 +145,7 @@ def test_parity_jax_object_from_a_dump(bench_mod, orc, tmp_path, monkeypatch):
     assert "error" not in pj, pj
     assert pj["rew_final_ref"] == 2.5 and pj["rew_final_ndiffuse"] == 6 and pj["golden"] == "golden_hopper_N8_H6.npz"
     assert pj["first_mismatch_stage"] == "6_contact_velocity" or pj["first_mismatch_stage"] == "contact:6_contact_velocity"
-    assert pj["fitted_flags"] == planted and pj["fitted"] == ["contact6_gauss_seidel"] and pj["fitted_first_mismatch_stage"] is None
+    assert pj["fitted_flags"] == planted and pj["fitted"] == ["contact_avg", "contact6_gauss_seidel"] and pj["fitted_first_mismatch_stage"] is None
     # teacher-forced under the fitted word: the checker reproduces the "reference" exactly
     assert pj["flags_of_the_teacher_forced_model"] == planted and pj["max_rel"] < 1e-6 and pj["within_tolerance"] is True
     assert pj["records"]["reverse_once_steps"] == 1 and pj["records"]["substep_stages"] and pj["records"]["settled_substep"]

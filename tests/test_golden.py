@@ -134,26 +134,30 @@ def test_compare_golden_localises_a_mismatch(orc, tmp_path, name):
     ("hopper", 8, 20, 0.0), ("hopper", 8 | 4, 20, 0.0), ("humanoidrun", 0, 10, 0.3)])
 def test_compare_golden_search_finds_the_planted_switches(orc, tmp_path, name, planted, steps, action):
     """tools/compare_golden.py --search (round-3 verdict item 3): a golden whose "reference" decides some of DESIGN.md §9's
-    code-level guesses the other way — planted here by producing the file with the checker under that flag word — is
-    replayed under all 64 combinations of the specification switches; the best-ranked one must reproduce the file (every
-    stage within tolerance), must contain every planted switch that acts on this state, and the default must NOT fit
-    (unless nothing was planted: then the default wins)."""
+    code-level guesses the other way — planted here by producing the file with the checker under the default word with the
+    `planted` switches FLIPPED (word = DEFAULT_SPEC ^ planted: since round 6 the default has contact_avg set, so planting 4
+    means a "reference" that sums) — is replayed under all 64 words; the best-ranked one must reproduce the file (every stage
+    within tolerance), must flip nothing that was not planted, and the default word must NOT fit (unless nothing was planted:
+    then the default wins)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import compare_golden
+    from mbd_hip.model import DEFAULT_SPEC
+    word = DEFAULT_SPEC ^ planted
     f = str(tmp_path / f"golden_{name}_N1_H1.npz")
-    _synthetic_stage_file(orc, f, name, flags=planted, steps=steps, action=action)
+    _synthetic_stage_file(orc, f, name, flags=word, steps=steps, action=action)
     rows = compare_golden.search(f, 1e-6)
     best = rows[0]
     assert best[2] is None, rows[:4]
     by_flags = {r[0]: r for r in rows}
-    assert by_flags[planted][2] is None                      # the planted combination fits ...
+    assert by_flags[word][2] is None                         # the planted word fits ...
+    flipped = best[0] ^ DEFAULT_SPEC
     if planted:
-        assert by_flags[0][2] is not None, "the planted switches did not act on this state"
-        assert best[0] & planted == best[0], rows[:4]        # ... and the winner asks for nothing that was not planted
-        # every planted switch the winner drops must be one that does not act here (the file fits without it)
+        assert by_flags[DEFAULT_SPEC][2] is not None, "the planted switches did not act on this state"
+        assert flipped & planted == flipped, rows[:4]        # ... and the winner flips nothing that was not planted
+        # every planted switch the winner leaves alone must be one that does not act here (the file fits without flipping it)
         for r in rows:
             if r[2] is None:
-                assert r[0] & best[0] == best[0], (best, r)   # all fitting combinations contain the winner's switches
+                assert (r[0] ^ DEFAULT_SPEC) & flipped == flipped, (best, r)   # all fitting words flip the winner's switches
     else:
-        assert best[0] == 0
+        assert best[0] == DEFAULT_SPEC

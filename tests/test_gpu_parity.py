@@ -1816,8 +1816,8 @@ def model_of(name, bits):
                          warn_unstable=False, spec_flags=bits)
     return load_model(name).with_spec(bits)
 for name, B, bits in (("hopper", 80, W), ("halfcheetah", 72, W), ("walker2d", 40, W), ("ant", 44, W), ("humanoidstandup", 36, W),
-                      ("humanoidrun", 48, W), ("ant", 4200, W), ("hopper", 64, 0), ("humanoidstandup", 24, 0), ("hopper", 48, W ^ 16),
-                      ("halfcheetahCA", 56, W), ("halfcheetahCA", 40, 0)):
+                      ("humanoidrun", 48, W), ("ant", 4200, W), ("hopper", 64, W ^ 4), ("humanoidstandup", 24, W ^ 4), ("hopper", 48, W ^ 16),
+                      ("halfcheetahCA", 56, W), ("halfcheetahCA", 40, W ^ 4)):
     env = RigidBodyEnv(name.replace("CA", ""), model=model_of(name, bits))
     st = env.reset(_capi.prng_key(5))
     H = 50 if B < 1000 else 6
@@ -1835,11 +1835,11 @@ np.savez(out, **res)
 
 
 def _tuned_variants():
-    """(file name, word) of the MBD_TUNED_SPEC builds to hold to the checker: the one build() keeps (contact_avg) and whatever
+    """(file name, word) of the MBD_TUNED_SPEC builds to hold to the checker: the one build() keeps (word 0: summed contacts) and whatever
     `python tools/build_variant.py spec<word> -DMBD_TUNED_SPEC=<word>` left beside it."""
     import glob, re
     from conftest import ROOT
-    out = [("libmbd_hip_avg.so", 4)]
+    out = [("libmbd_hip_sum.so", 0)]
     for f in sorted(glob.glob(os.path.join(ROOT, "model-based-diffusion_amd", "lib", "variants", "libmbd_hip_spec*.so"))):
         m = re.search(r"libmbd_hip_spec(\d+)\.so$", f)
         if m:
@@ -1849,20 +1849,21 @@ def _tuned_variants():
 
 @pytest.mark.parametrize("lib_name,word", _tuned_variants())
 def test_tuned_spec_variant_is_bit_exact_to_the_flagged_checker(gpu, orc_omp, tmp_path, lib_name, word):
-    """Round 6: the tuned kernels compile a word of specification switches in, MBD_TUNED_SPEC — 0 in the library,
-    contact_avg (4) in lib/variants/libmbd_hip_avg.so, which build() keeps beside it.  Under the variant a model flagged 4 runs
-    the TUNED instantiations (planar packed pairs with their early-out, the humanoids', ant's, the helper-lane form, two
-    candidates per lane at 4200 ant candidates) and must equal the checker run with flag 4, bit for bit; a model flagged 0 or
-    4 ^ 16 runs the general SPEC instantiations there and must equal the checker too.  The library under test answers 0.
+    """Round 6: the tuned kernels compile a word of specification switches in, MBD_TUNED_SPEC — MBD_DEFAULT_SPEC =
+    contact_avg (4) in the library, 0 (a link's contacts summed: rounds 1-5) in lib/variants/libmbd_hip_sum.so, which build()
+    keeps beside it.  Under the variant a model carrying the variant's word runs the TUNED instantiations (planar packed pairs
+    with their early-out, the humanoids', ant's, the helper-lane form, two candidates per lane at 4200 ant candidates, four
+    colliders on a link) and must equal the checker run with that word, bit for bit; a model with another word (the default 4,
+    word ^ 16) runs the general SPEC instantiations there and must equal the checker too.  The library under test answers 4.
     (Other words — gauss_seidel, friction_vel_bound, restitution_min and their unions — build the same way; a variant named
     libmbd_hip_spec<word>.so found beside it is held to the same bar: round 6 ran 60 = all four.)"""
     import subprocess, sys
     from conftest import ROOT, load_model
     from oracle.planner import OracleEnv
     pkg = os.path.join(ROOT, "model-based-diffusion_amd")
-    assert gpu.load().mbd_tuned_spec() == 0
+    assert gpu.load().mbd_tuned_spec() == 4
     avg = os.path.join(pkg, "lib", "variants", lib_name)
-    assert os.path.exists(avg), "build() leaves the contact_avg build under lib/variants/"
+    assert os.path.exists(avg), "build() leaves the summed-contacts build under lib/variants/"
     env = dict(os.environ)
     env["MBD_HIP_LIB"] = avg
     out = str(tmp_path / "avg.npz")

@@ -38,13 +38,13 @@ def score_tol(rewss, temp, sigma, demo=False, guard=True):
     std = 1.0 if (guard and std < 1e-4) else max(std, 1e-12)   # (:112; path_integral.py:123 has no such guard)
     raw = 4.0 * 2.0 ** -24 * float(np.abs(rewss).max()) / (std * temp)
     # (round-5 advice: the data-derived bound on the weighted mean grows with a low-spread step — humanoidstandup: 3.6e-4 — so
-    # it is CAPPED at 1e-4 absolute, and the whole-run tests also hold each file to twice the error recorded for it: RECORDED_Y)
-    return 2e-5 + raw + (1e-3 if demo else 0.0), min(1e-4, max(1e-5, 2e-6 + float(sigma) * raw))
+    # it is CAPPED at 2e-4 absolute, and the whole-run tests also hold each file to twice the error recorded for it: RECORDED_Y)
+    return 2e-5 + raw + (1e-3 if demo else 0.0), min(2e-4, max(1e-5, 2e-6 + float(sigma) * raw))
 
 
 # max |Ybar_{i-1} - file| over a file's recorded steps, as measured in round 6 (checker, f32): a regression INSIDE score_tol's bound
 # still shows when the error of a file doubles
-RECORDED_Y = {"humanoidrun": 8.4e-7, "hopper": 1.6e-6, "walker2d": 4.8e-7, "humanoidstandup": 8.4e-5, "cartpole": 3.8e-6,
+RECORDED_Y = {"humanoidrun": 8.4e-7, "hopper": 6.9e-7, "walker2d": 6.3e-7, "humanoidstandup": 1.02e-4, "cartpole": 3.8e-6,
               "humanoidtrack": 6.1e-6, "humanoidtrack_demo": 4.5e-7}
 
 

@@ -37,7 +37,8 @@ def test_contact_switches_only_touch_links_with_several_contacts(orc, name):
     each — not a bit changes — while hopper's and walker2d's feet (two spheres: the planar restatement) and
     humanoidstandup's torso (five: the 3-D one) do once they stand / lie on both."""
     m = load_model(name)
-    base = _roll(orc, m, 100, scale=0.1)  # (gentle actions: the models settle onto their feet / their back)
+    assert int(m.fields["flags"]) & 252 == spec_bits("contact_avg")   # (the default word since round 6: model.DEFAULT_SPEC)
+    base = _roll(orc, m.with_spec(0), 100, scale=0.1)  # (the summed Jacobi form; gentle actions: the models settle onto their feet / their back)
     for bits in (spec_bits("contact_avg"), spec_bits("contact6_gauss_seidel"), spec_bits("contact_avg", "contact6_gauss_seidel")):
         got = _roll(orc, m.with_spec(bits), 100, scale=0.1)
         assert np.isfinite(got).all()
@@ -52,7 +53,7 @@ def test_contact_avg_halves_the_correction_of_two_equal_contacts(orc):
     link with n equal contacts overshoots n-fold, damped by collide_scale); with the average the link moves by ONE
     contact's correction.  After the first substep in contact the summed correction is 4x the averaged one."""
     m = _compile(SLED.format(gx=0.0, gz=-9.81, mu=1.0))
-    ms0, ms1 = m.to_struct(), m.with_spec(spec_bits("contact_avg")).to_struct()
+    ms0, ms1 = m.with_spec(0).to_struct(), m.with_spec(spec_bits("contact_avg")).to_struct()
     st = orc.forward(ms0, m.init_q, np.zeros(6, np.float32))
     st[0, 2] -= 0.02   # all four spheres 2 cm into the floor, at rest
     g = -9.81 * 0.002 * 0.002  # (the fall of one substep)

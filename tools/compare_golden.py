@@ -4,11 +4,13 @@ i.e. which of DESIGN.md §9's guesses is wrong — after first comparing the com
 
     python tools/compare_golden.py tests/golden/golden_humanoidrun_N64_H50.npz [--tol 1e-5] [--flags N] [--search]
 
---flags N   replay under the specification switches N (include/mbd_hip.h mbd_model_flags / mbd_hip.model.SPEC_FLAGS:
-            contact_avg 4, contact6_gauss_seidel 8, friction_vel_bound 16, restitution_min 32, euler_extrinsic 64, gyroscopic 128)
+--flags N   replay under the word of specification switches N (include/mbd_hip.h mbd_model_flags / mbd_hip.model.SPEC_FLAGS:
+            contact_avg 4, contact6_gauss_seidel 8, friction_vel_bound 16, restitution_min 32, euler_extrinsic 64, gyroscopic 128);
+            without it: the model as compiled = the default word, 4 (contact_avg) since round 6
 --search    replay under EVERY combination of the six switches and rank them: most stages within tolerance first, then the
-            smallest error at the first mismatching stage, then the fewest switches — the line to read is the first one; a
-            winner other than "default" names the code-level guesses of DESIGN.md §9 that Brax decides the other way, and
+            smallest error at the first mismatching stage, then the fewest switches flipped against the default word — the line
+            to read is the first one; a winner other than the default word names the code-level guesses of DESIGN.md §9 that Brax
+            decides the other way, and
             the model is then recompiled with that flag word (mjcf.load(spec_flags=...)): no kernel or checker rewrite.
 
 Exit code 0: every stage within tolerance (--search: under the best combination); 1: a mismatch was reported; 2: the file
@@ -43,14 +45,16 @@ def _state(g, prefix):
                           axis=1).astype(np.float32)
 
 
-def compare(path, tol=1e-5, flags=0):
+def compare(path, tol=1e-5, flags=None):
     from mbd_hip.model import Model
     from oracle import oracle as orc_mod
     import ctypes as C
     g = np.load(path)
     name = os.path.basename(path).split("_")[1]
     with open(os.path.join(ROOT, "model-based-diffusion_amd", "assets", "compiled", f"{name}.json")) as f:
-        m = Model.from_json(f.read()).with_spec(flags)
+        m = Model.from_json(f.read())
+    if flags is not None:  # (None: the model as compiled — the default word, model.DEFAULT_SPEC)
+        m = m.with_spec(flags)
     ms = m.to_struct()
     L = m.n_links
     lines, first = [], None
@@ -161,7 +165,9 @@ def search(path, tol=1e-5):
             return [(0, [], first, 0, 0.0)]
         ok = len(order) if first is None else (order.index(first[0]) if first[0] in order else 0)
         rows.append((flags, spec_names(flags), first, ok, 0.0 if first is None else first[3]))
-    rows.sort(key=lambda r: (-r[3], r[4], bin(r[0]).count("1"), r[0]))
+    # (ties: the word closest to the default one — fewest switches flipped against model.DEFAULT_SPEC)
+    from mbd_hip.model import DEFAULT_SPEC
+    rows.sort(key=lambda r: (-r[3], r[4], bin(r[0] ^ DEFAULT_SPEC).count("1"), r[0]))
     return rows
 
 
@@ -171,11 +177,11 @@ if __name__ == "__main__":
         rows = search(sys.argv[1], tol)
         for flags, names, first, ok, err in rows[:12]:
             where = "all stages within tolerance" if first is None else f"first mismatch {first[0]} link {first[1]} {first[2]} err {err:.3g}"
-            print(f"flags {flags:3d} [{', '.join(names) or 'default'}]: {where}")
+            print(f"flags {flags:3d} [{', '.join(names) or 'none'}]{' = the default word' if flags == 4 else ''}: {where}")
         best = rows[0]
-        print(f"BEST: flags {best[0]} ({', '.join(best[1]) or 'the default specification'})")
+        print(f"BEST: flags {best[0]} ({', '.join(best[1]) or 'no switch set'}{': the default specification' if best[0] == 4 else ''})")
         sys.exit(0 if best[2] is None else (2 if best[2][0] == "none" else 1))
-    flags = int(sys.argv[sys.argv.index("--flags") + 1]) if "--flags" in sys.argv else 0
+    flags = int(sys.argv[sys.argv.index("--flags") + 1]) if "--flags" in sys.argv else None
     lines, first = compare(sys.argv[1], tol, flags)
     print("\n".join(lines))
     sys.exit(0 if first is None else (2 if first[0] == "none" else 1))

@@ -22,7 +22,7 @@ ranaway_seeds = []
 blown_seeds, blown_default = [], []
 kinds = {}
 for seed in range(first, first + count):
-    bits = 0
+    bits = 4  # (model.DEFAULT_SPEC: the word the shipped library's tuned and general non-SPEC instantiations compile in)
     if mode.endswith("spec"):  # a random subset of the specification switches (include/mbd_hip.h mbd_model_flags)
         bits = int(np.random.default_rng(1000 + seed).integers(1, 64)) * 4
     if forced_bits is not None:
@@ -50,7 +50,7 @@ for seed in range(first, first + count):
     if not np.isfinite(ref).all():
         blown += 1
         blown_seeds.append((seed, bits))
-        if bits == (forced_bits or 0):  # the DEFAULT specification (or the forced word) on a model the generator called stable: an instability of the default, not of a switch
+        if bits == (4 if forced_bits is None else forced_bits):  # the DEFAULT specification (or the forced word) on a model the generator called stable: an instability of the default, not of a switch
             blown_default.append(seed)
     # RUNAWAYS: a model whose motion leaves the numerical contract's ranges (the kernels' short division / square-root
     # sequences are the correctly rounded results for magnitudes up to ~1e8 — a free slide under a strong motor passes 1e5 m

@@ -1,5 +1,5 @@
 """What a specification switch costs: steps/s of a plan whose model carries the flag word, for every single flag.
-A model whose flags differ from the library's tuned default (MBD_TUNED_SPEC, 0 in the shipped build) runs the general SPEC
+A model whose flags differ from the library's tuned word (MBD_TUNED_SPEC: MBD_DEFAULT_SPEC = contact_avg in the shipped build) runs the general SPEC
 instantiations (16-lane groups, shuffle exchange, every switch read at run time); one that matches runs the tuned kernels.
 usage (GPU box): python tools/gpu_spec_cost.py [--lib PATH]   (the table goes to stdout)"""
 import os
@@ -22,7 +22,7 @@ def main():
     from mbd_hip.planners.mbd_planner import Args, Plan
     cases = [("hopper", 512, 0.1), ("halfcheetah", 1024, 0.4), ("walker2d", 1024, 0.1), ("ant", 1024, 0.1),
              ("humanoidstandup", 1024, 0.1), ("humanoidrun", 1024, 0.1)]
-    names = {0: "default (0)", 4: "contact_avg (4)", 8: "gauss_seidel (8)", 16: "friction_vel_bound (16)", 32: "restitution_min (32)",
+    names = {4: "contact_avg (4: the default)", 0: "summed (0)", 8: "gauss_seidel (8)", 16: "friction_vel_bound (16)", 32: "restitution_min (32)",
              64: "euler_extrinsic (64)", 128: "gyroscopic (128)"}
     print(f"library: {os.environ.get('MBD_HIP_LIB', 'lib/libmbd_hip.so')}")
     print("| env, N | " + " | ".join(names[b] for b in names) + " |")
