@@ -23,7 +23,7 @@ REWARD_KINDS = {"humanoidrun": 0, "hopper": 1, "halfcheetah": 2, "humanoidtrack"
                 "humanoidstandup": 4, "cartpole": 5, "ant": 6}
 
 # mbd_model_flags (include/mbd_hip.h).  The SPEC_* bits are the specification switches of DESIGN.md §9: code-level guesses
-# about Brax's positional pipeline, default 0; tools/compare_golden.py --search tries every combination against a golden.
+# about Brax's positional pipeline (default word: DEFAULT_SPEC below); tools/compare_golden.py --search tries every combination against a golden.
 FLAG_RESET_QUAT_RAW, FLAG_PLANAR = 1, 2
 SPEC_FLAGS = {"contact_avg": 4, "contact6_gauss_seidel": 8, "friction_vel_bound": 16, "restitution_min": 32,
               "euler_extrinsic": 64, "gyroscopic": 128}

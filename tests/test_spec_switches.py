@@ -1,6 +1,6 @@
 """The specification switches (include/mbd_hip.h mbd_model_flags; round-3 verdict item 3): the code-level
 guesses about Brax's positional pipeline as flag bits of the model, honoured by the checker (here) and the kernels
-(tests/test_gpu_parity.py) alike.  Default 0 is the specification the tuned kernels compile in (rounds 1-4's, with stage (6) Jacobi per
+(tests/test_gpu_parity.py) alike.  The default word (model.DEFAULT_SPEC = contact_avg since round 6) is the specification the shipped tuned kernels compile in (rounds 1-4's, with stage (6) Jacobi per
 link since round 5: the committed self_* goldens hold it bit for bit); every bit selects a named alternative whose effect is pinned here to what it is supposed to be, so that
 tools/compare_golden.py --search can tell the alternatives apart when a real golden arrives."""
 
