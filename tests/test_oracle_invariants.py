@@ -312,7 +312,7 @@ def test_only_the_feet_collide_is_a_guess_with_consequences(orc, name):
     sinks through the floor.  `collide_all_capsules` (mjcf.load / specs.SPECS) is the switch a golden vector can flip: every
     capsule end a sphere collider.  Under random actions for 100 control steps some of 16 candidates of the shipped model put
     their torso origin BELOW the floor; with the switch none does — it rests on its capsules (tools/model_guess_report.py:
-    what that does to the plans — 92-100 % of a hopper plan's candidates dip their torso below z = 0)."""
+    what that does to the plans — 95-100 % of a hopper plan's candidates dip their torso below z = 0)."""
     import sys
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     import model_guess_report as mg
