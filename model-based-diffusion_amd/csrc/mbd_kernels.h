@@ -1633,9 +1633,9 @@ __global__ __launch_bounds__(256) void rollout_kernel(RolloutParams P) {
 #pragma unroll
           for (int j = 0; j < MAXCOL; ++j) n_act += con_act[j] ? 1 : 0;
           if (sp_avg) {  // the average over the link's active contacts (two or more; one: untouched)
-            const float inv_n = 1.0f / (float)(n_act > 1 ? n_act : 1);
-            cd_p = sel3(n_act >= 2, scale(cd_p, inv_n), cd_p);
-            cd_th = sel3(n_act >= 2, scale(cd_th, inv_n), cd_th);
+            const float inv_n = 1.0f / (float)(n_act > 1 ? n_act : 1);  // (exactly 1 for a single contact: no select needed)
+            cd_p = scale(cd_p, inv_n);
+            cd_th = scale(cd_th, inv_n);
           }
         }
         p = add(p, cd_p);  // zero corrections on links without colliders

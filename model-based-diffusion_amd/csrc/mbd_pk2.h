@@ -519,9 +519,8 @@ __global__ __launch_bounds__(256, WPE) void rollout_pk2_kernel(RolloutParams P) 
 #pragma unroll
           for (int j = 0; j < MAXCOL; ++j) { nx += con_act[j].x ? 1 : 0; ny += con_act[j].y ? 1 : 0; }
           const f2 inv_n = mk2(1.0f / (float)(nx > 1 ? nx : 1), 1.0f / (float)(ny > 1 ? ny : 1));
-          const b2 many{nx >= 2, ny >= 2};
-          cd_p = sel3(many, scale2(cd_p, inv_n), cd_p);
-          cd_th = sel3(many, scale2(cd_th, inv_n), cd_th);
+          cd_p = scale2(cd_p, inv_n);    // (inv_n is exactly 1 for a single contact: no select needed)
+          cd_th = scale2(cd_th, inv_n);
         }
         p = add2(p, cd_p);
         r = qrotvec2_qm<QM>(r, cd_th, q_worst);

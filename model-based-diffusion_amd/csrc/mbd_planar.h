@@ -497,8 +497,10 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
         if constexpr (SPEC_AVG && MAXCOL == 2) {
           if (sp_avg) {  // both touch: the average of the link's two velocity changes, v6 + (v - v6) / 2
             const bool both = cact[C0] && cact[C1];
-            vx = both ? ffma(vx - vx6, 0.5f, vx6) : vx;
-            vz = both ? ffma(vz - vz6, 0.5f, vz6) : vz;
+            const f2 v62 = mk2(vx6, vz6);
+            const f2 a2 = fma2(mk2(vx, vz) - v62, bc2(0.5f), v62);  // (the linear pair packed: same roundings per component)
+            vx = both ? a2.x : vx;
+            vz = both ? a2.y : vz;
             om = both ? ffma(om - om6, 0.5f, om6) : om;
           }
         }
@@ -550,8 +552,16 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
             cdz = act1[Q] ? ffma(im_c, Piz.y, cdz) : cdz;
             cdth = act1[Q] ? cdth + dth.y : cdth;
             if constexpr (!SPEC && MAXCOL == 2 && (MBD_TUNED_SPEC & MBD_FLAG_CONTACT_AVG) != 0) {  // both touch: half the summed correction
-              const bool both = act0[Q] && act1[Q];  // (SPEC, and four colliders: averaged below over the link's count)
-              cdx = both ? cdx * 0.5f : cdx; cdz = both ? cdz * 0.5f : cdz; cdth = both ? cdth * 0.5f : cdth;
+              // (SPEC, and four colliders: averaged below over the link's count.  One select of the factor — times 1 is exact —
+              // and a packed product: 3 instructions where three selected products took 6)
+              // (not in the early-out instantiations: packing the corrections there costs their common path three moves)
+              const float half = (act0[Q] && act1[Q]) ? 0.5f : 1.0f;
+              if constexpr (EO) {
+                cdx = cdx * half; cdz = cdz * half; cdth = cdth * half;
+              } else {
+                const f2 c2 = mk2(cdx, cdz) * bc2(half);
+                cdx = c2.x; cdz = c2.y; cdth = cdth * half;
+              }
             }
             cposx[2 * Q] = posx.x; cposx[2 * Q + 1] = posx.y; cposz[2 * Q] = posz.x; cposz[2 * Q + 1] = posz.y;
             cdlam[2 * Q] = dlam.x; cdlam[2 * Q + 1] = dlam.y; cact[2 * Q] = act0[Q]; cact[2 * Q + 1] = act1[Q];
@@ -621,7 +631,7 @@ __global__ __launch_bounds__(256) void rollout_planar_kernel(RolloutParams P) {
 #pragma unroll
             for (int j = 0; j < MAXCOL; ++j) n_act += cact[j] ? 1 : 0;
             const float inv_n = 1.0f / (float)(n_act > 1 ? n_act : 1);
-            cdx = n_act >= 2 ? cdx * inv_n : cdx; cdz = n_act >= 2 ? cdz * inv_n : cdz; cdth = n_act >= 2 ? cdth * inv_n : cdth;
+            cdx = cdx * inv_n; cdz = cdz * inv_n; cdth = cdth * inv_n;  // (inv_n is exactly 1 for a single contact)
           }
         }
         if constexpr (!EO) {
