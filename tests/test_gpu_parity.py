@@ -452,7 +452,11 @@ def test_run_diffusion_humanoidrun_end_to_end_short(gpu, orc):
     ("hopper", 512, 50, 100, 0.1, False, 1),             # BASELINE config 2
     ("halfcheetah", 1024, 50, 100, 0.4, False, 2),       # config 3
     ("humanoidtrack", 2048, 50, 100, 0.1, True, 3),      # config 5's plan on one GPU
-    ("humanoidrun", 4096, 50, 40, 0.1, False, 4)])       # config 4's size, 39 steps
+    ("humanoidrun", 4096, 50, 40, 0.1, False, 4),        # config 4's size, 39 steps
+    # round 6, the row-(f) envs at their reference sizes: walker2d (one candidate per wavefront + contact early-out), ant (the
+    # reference's default env_name), humanoidstandup (helper lanes, five colliders on the torso, averaged)
+    ("walker2d", 1024, 50, 16, 0.1, False, 5), ("ant", 1024, 50, 10, 0.1, False, 6), ("humanoidstandup", 1024, 50, 10, 0.1, False, 7),
+    ("hopper", 2048, 50, 16, 0.1, False, 8)])            # (two candidates per wavefront)
 def test_whole_runs_at_full_size_bitexact(gpu, orc_omp, name, N, H, Nd, temp, demo, seed):
     """WHOLE planning runs at the full size of the BASELINE configs, free-running (every step from the previous step's own
     result, mbd_planner.py:138-151) and the final evaluation (:179-180): the product's run_diffusion through the C ABI against
